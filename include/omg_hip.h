@@ -1,0 +1,249 @@
+/*
+ * omg_hip.h — C ABI of libomg_hip.so: the MI355X (gfx950) kernels behind OMG's
+ * two-stage SDXL denoising hot path (boundary row B5).
+ *
+ * The reference (kongzhecn/OMG) is pure Python with no native code; its FFI for
+ * this path is "torch ops called from diffusers modules".  Each entry point
+ * below names the reference call site (file:line under /root/reference, or the
+ * diffusers==0.25.0 symbol that call site dispatches to) that it replaces.
+ *
+ * Conventions (all entry points)
+ *   - return 0 on success, a negative OMG_E* code on error; never throw,
+ *     never allocate, never synchronise, never touch the host heap: safe under
+ *     hipGraph capture.
+ *   - every pointer is a DEVICE pointer owned by the caller; sizes are in
+ *     elements of the named dtype unless suffixed _bytes.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ *   - `dtype` is OMG_F16 or OMG_BF16: the storage type of activations and
+ *     weights.  All contractions accumulate in fp32 on MFMA.
+ *   - activations inside the UNet are NHWC ("pixels × channels", i.e. the
+ *     (B, H*W, C) token layout the transformer blocks want); the NCHW latent
+ *     layout of the reference exists only at conv_in / conv_out.
+ */
+#ifndef OMG_HIP_H
+#define OMG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMG_ABI_VERSION 1
+
+enum { OMG_F16 = 0, OMG_BF16 = 1, OMG_F32 = 2 /* only where a signature says so */ };
+
+enum {
+  OMG_OK = 0,
+  OMG_EINVAL = -1,   /* bad shape / alignment / null pointer          */
+  OMG_EDTYPE = -2,   /* unsupported dtype                              */
+  OMG_ELAUNCH = -3   /* hipLaunchKernel reported an error              */
+};
+
+/* activation applied in the GEMM / conv epilogue */
+enum {
+  OMG_ACT_NONE = 0,
+  OMG_ACT_SILU = 1,  /* x*sigmoid(x)   — TimestepEmbedding.act (diffusers embeddings.py) */
+  OMG_ACT_GEGLU = 2  /* out[:, j] = h[:, j] * gelu(h[:, N/2 + j]); W rows pre-packed by omg_pack_geglu_rows */
+};
+
+int omg_abi_version(void);
+/* last launch error string (thread-unsafe, debugging aid) */
+const char* omg_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * omg_gemm — C[M,N] = epi( A[M,K] · W[N,K]^T  (+ A2[M,K2] · W2[N,K2]^T) )
+ *
+ * Replaces every nn.Linear on the path: attn.to_q/to_k/to_v/to_out[0]
+ * (src/pipelines/lora_pipeline.py:98-124), Transformer2DModel.proj_in/out,
+ * FeedForward GEGLU + out Linear, ResnetBlock2D.time_emb_proj, TimestepEmbedding
+ * (diffusers 0.25.0).  The second K-segment is the PEFT LoRA branch
+ * `base(x) + s·B(A(x))` (concept_models.set_adapters, lora_pipeline.py:588-591)
+ * folded into the same MFMA accumulator: A2 = x·A_c^T (rank-r), W2 = s·B_c.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  int32_t M, N, K;            /* K % 8 == 0, N % 8 == 0                              */
+  const void* A;  int64_t lda;
+  const void* W;  int64_t ldw;
+  /* optional LoRA segment (K2 == 0 disables) */
+  const void* A2; int64_t lda2;
+  const void* W2; int64_t ldw2;
+  int32_t K2;
+  int32_t a2_col_block;       /* >0: A2 column offset = (n / a2_col_block) * K2 (fused q|k|v) */
+  /* per-sample ("group") selection.  M = groups * rows_per_group.            */
+  int32_t groups;             /* >=1                                                  */
+  int32_t rows_per_group;
+  const int32_t* group_adapter; /* [groups] adapter id or -1 (no LoRA); NULL = id 0  */
+  int64_t w_adapter_stride;   /* W_eff  = W  + id * stride (LoRA-down GEMM); 0 = shared */
+  int64_t w2_adapter_stride;  /* W2_eff = W2 + id * stride                             */
+  /* epilogue */
+  const void* bias;           /* [N] or NULL                                          */
+  const void* group_bias; int64_t ldgb; /* [groups, N] per-sample bias (temb) or NULL  */
+  const void* residual; int64_t ldr;    /* [M, N_out] or NULL                          */
+  int32_t act;                /* OMG_ACT_*                                            */
+  float out_scale;            /* applied before the residual add                      */
+  void* C; int64_t ldc;       /* [M, N_out]; N_out = N/2 for GEGLU else N             */
+} omg_gemm_args;
+
+int omg_gemm(const omg_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------
+ * omg_conv2d — NHWC implicit-GEMM convolution (3x3 pad 1, or 1x1), stride 1|2,
+ * optional fused nearest-2x upsample of the input and fused channel-concat of
+ * two inputs (the UNet skip connection), same epilogues as omg_gemm.
+ *
+ * Replaces ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D.conv,
+ * Upsample2D (F.interpolate nearest + conv) and torch.cat([h, res], dim=1) in
+ * CrossAttnUpBlock2D/UpBlock2D — all inside the `self.unet(...)` call at
+ * src/pipelines/lora_pipeline.py:546-566 (diffusers 0.25.0 unet_2d_blocks.py).
+ * W is [Cout][ky][kx][C1+C2] (packed by the host from the diffusers OIHW key).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  int32_t B, Hin, Win;        /* input spatial size (before upsample)                 */
+  int32_t C1, C2;             /* channels of X1 and (optional) X2; both % 64 == 0     */
+  int32_t Hout, Wout, Cout;   /* Cout % 8 == 0                                        */
+  int32_t ksize;              /* 1 or 3                                               */
+  int32_t stride;             /* 1 or 2                                               */
+  int32_t upsample;           /* 1: conv runs on nearest-2x-upsampled input           */
+  const void* X1; const void* X2;
+  const void* W;              /* [Cout][ksize*ksize*(C1+C2)]                           */
+  const void* bias;           /* [Cout] or NULL                                       */
+  const void* group_bias; int64_t ldgb; /* [B, Cout] per-sample bias (time emb) or NULL */
+  const void* residual;       /* NHWC [B,Hout,Wout,Cout] or NULL                      */
+  float out_scale;
+  void* Y;                    /* NHWC [B,Hout,Wout,Cout]                              */
+} omg_conv2d_args;
+
+int omg_conv2d(const omg_conv2d_args* a, void* stream);
+
+/* ------------------------------------------------------------------------
+ * omg_attn_fwd — softmax(Q K^T * scale) V, head_dim 64, never materialising
+ * the probabilities, with prompt-to-prompt "probability borrowing".
+ *
+ * Replaces, in one kernel: attn.get_attention_scores (baddbmm + softmax),
+ * the controller's in-place edit of the conditional half of the probabilities,
+ * and torch.bmm(probs, value) — src/pipelines/lora_pipeline.py:114-116 with
+ * src/prompt_attention/p2p_attention.py:28-40,124-138.  With mapper = I and
+ * alpha = 1 (always, in OMG flows) the controller's
+ * `probs[edit] := probs[base]` is "sample b attends with the Q,K of sample
+ * qk_src[b] but its own V".  Also replaces F.scaled_dot_product_attention /
+ * xformers in the concept UNet (src/ip_adapter/attention_processor.py:273,383,399)
+ * — `accumulate` implements IPAttnProcessor2_0's `text + scale*ip` (:409).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;
+  int32_t B, heads, Nq, Nkv;  /* head_dim is 64                                       */
+  const void* Q; int64_t ldq; int64_t q_bstride;   /* row stride / batch stride (elements) */
+  const void* K; int64_t ldk; int64_t k_bstride;
+  const void* Vt;             /* [B, heads, 64, Nkv_pad] keys contiguous, zero padded  */
+  int32_t Nkv_pad;            /* % 64 == 0                                            */
+  const int32_t* qk_src;      /* device [B]: batch index supplying Q,K; NULL = identity */
+  float scale;
+  int32_t accumulate;         /* 0: O = out_scale*attn ; 1: O += out_scale*attn       */
+  float out_scale;
+  void* O; int64_t ldo; int64_t o_bstride;
+} omg_attn_args;
+
+int omg_attn_fwd(const omg_attn_args* a, void* stream);
+
+/* V[B, Nkv, (head, 64)] (row stride ldv) -> Vt[B, heads, 64, Nkv_pad], zero padded. */
+int omg_transpose_v(int dtype, const void* V, int64_t ldv, int64_t v_bstride,
+                    int B, int heads, int Nkv, int Nkv_pad, void* Vt, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Normalisation.  GroupNorm (NHWC, fp32 statistics, deterministic two-stage
+ * reduction) replaces ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2D
+ * .norm and UNet conv_norm_out + conv_act; LayerNorm replaces
+ * BasicTransformerBlock.norm1/2/3 (diffusers 0.25.0 attention.py).
+ * ---------------------------------------------------------------------- */
+/* workspace: floats, at least omg_groupnorm_ws_floats(B, groups, HW) */
+int64_t omg_groupnorm_ws_floats(int B, int groups, int HW);
+/* X may be the channel-concat of X1 (C1) and X2 (C2) — pass X2=NULL,C2=0 otherwise */
+int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, int C2,
+                  int B, int HW, int groups, float eps,
+                  const void* gamma, const void* beta, int silu,
+                  float* workspace, void* Y, void* stream);
+int omg_layernorm(int dtype, const void* X, int64_t ldx, int M, int C, float eps,
+                  const void* gamma, const void* beta, void* Y, int64_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Boundary convolutions (NCHW latents <-> NHWC features).
+ * conv_in : UNet2DConditionModel.conv_in  (4 -> C0, 3x3), input NCHW fp32|T.
+ * conv_out: UNet2DConditionModel.conv_out (C0 -> 4, 3x3) on the already
+ *           normalised+SiLU'd NHWC features, output NCHW in fp32.
+ * ---------------------------------------------------------------------- */
+int omg_conv_in(int dtype, const void* X_nchw, int x_is_f32, int B, int Cin, int H, int W,
+                const void* Wt /*[Cout][3][3][Cin]*/, const void* bias, int Cout,
+                void* Y_nhwc, void* stream);
+int omg_conv_out(int dtype, const void* X_nhwc, int B, int H, int W, int Cin,
+                 const void* Wt /*[Cout][3][3][Cin]*/, const void* bias, int Cout,
+                 float* Y_nchw, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Small elementwise pieces of the time/text conditioning path
+ * (diffusers embeddings.py get_timestep_embedding, flip_sin_to_cos=True,
+ *  downscale_freq_shift=0; and `self.nonlinearity(temb)` in ResnetBlock2D).
+ * ---------------------------------------------------------------------- */
+int omg_timestep_embedding(int dtype, const float* t, int n, int dim, void* out, int64_t ldo, void* stream);
+int omg_silu(int dtype, const void* x, void* y, int64_t n, void* stream);
+/* dst[r, col0 : col0+cols] = src[r, 0:cols]  (row-wise copy with strides, elements) */
+int omg_copy2d(int dtype, const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
+
+/* ------------------------------------------------------------------------
+ * omg_fuse_cfg_step — region-masked noise fusion + classifier-free guidance +
+ * scheduler update + next model input, one launch, zero host syncs.
+ *
+ * Replaces src/pipelines/lora_pipeline.py:568-607 (fusion, incl. get_region_mask
+ * :674-681 and the nearest mask resize), :610-612 (CFG), :615 (scheduler.step)
+ * and :491-492 (cat + scale_model_input of the next iteration); identical block
+ * in src/pipelines/instantid_pipeline.py:618-707.
+ *
+ * noise_pred : fp32 [4,C,H,W] = [unc0, unc1, cond0, cond1]
+ * region_pred: K pointers to fp32 [2,C,H,W] = [unc, cond] (NULL entry = concept without a mask)
+ * masks      : K pointers to fp32 [Hm,Wm] full-resolution {0,1} masks (NULL = None)
+ * coef       : device table [n_steps][4] = {cx, ce, cin_next, unused}; row = *step_idx
+ *              latents' = cx*latents + ce*eps ; model_input' = cin_next * latents'
+ * step_idx   : device int; read, and incremented when `advance` != 0
+ * ---------------------------------------------------------------------- */
+#define OMG_MAX_CONCEPTS 8
+typedef struct {
+  int32_t C, H, W;            /* latent channels (4) and size                         */
+  int32_t Hm, Wm;             /* mask size (e.g. 1024 x 1024)                          */
+  int32_t n_concepts;
+  int32_t fuse;               /* 0: plain CFG step; 1: masked fusion (i > 15, stage 2) */
+  float guidance_scale;
+  const float* noise_pred;
+  const float* region_pred[OMG_MAX_CONCEPTS];
+  const float* masks[OMG_MAX_CONCEPTS];
+  const float* coef;
+  int32_t* step_idx;
+  int32_t advance;
+  float* latents;             /* fp32 [2,C,H,W], updated in place                     */
+  int32_t out_dtype;          /* dtype of model_input_next                            */
+  void* model_input_next;     /* [4,C,H,W] = cat([latents']*2) * cin_next  (may be NULL) */
+  float* fused_noise_out;     /* optional fp32 [2,C,H,W]: the fused (unc1, cond1) — parity tap */
+} omg_step_args;
+
+int omg_fuse_cfg_step(const omg_step_args* a, void* stream);
+
+/* model_input[4,C,H,W] (dtype) = cin * cat([latents]*2)  — first iteration of the loop */
+int omg_scale_model_input(int dtype, const float* latents, const float* coef_cin, int n_per_sample, void* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Protocol-mode pieces (materialised probabilities) so that ANY controller
+ * object — including the reference's own AttentionReplace with a non-identity
+ * mapper — can be driven through RegionControlNet_AttnProcessor's exact
+ * sequence (lora_pipeline.py:114-116): scores -> softmax -> controller -> bmm.
+ * ---------------------------------------------------------------------- */
+/* P[bh, q, kv] = softmax_kv(scale * Q[bh,q,:] . K[bh,kv,:])   (Q/K as in omg_attn_fwd) */
+int omg_attn_probs(const omg_attn_args* a, void* P /*[B*heads, Nq, Nkv] dtype*/, void* stream);
+/* O[b, q, h*64+d] = sum_kv P[bh,q,kv] * V[b,kv,h*64+d] */
+int omg_attn_apply_probs(int dtype, const void* P, const void* V, int64_t ldv, int64_t v_bstride,
+                         int B, int heads, int Nq, int Nkv, void* O, int64_t ldo, int64_t o_bstride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMG_HIP_H */

@@ -1,0 +1,60 @@
+// common.h — shared device/host helpers for libomg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/omg_hip.h"
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define OMG_DEV __device__ __forceinline__
+
+template <typename T> struct Vec;
+template <> struct Vec<f16> {
+  using v8 = f16x8; using v4 = f16x4;
+  static OMG_DEV f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Vec<bf16> {
+  using v8 = bf16x8; using v4 = bf16x4;
+  static OMG_DEV f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T> OMG_DEV float to_f32(T x) { return (float)x; }
+template <typename T> OMG_DEV T from_f32(float x) { return (T)x; }
+
+// 16-byte vector <-> 8 floats
+template <typename T> OMG_DEV void unpack8(u32x4 raw, float (&f)[8]) {
+  typename Vec<T>::v8 v = __builtin_bit_cast(typename Vec<T>::v8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> OMG_DEV u32x4 pack8(const float (&f)[8]) {
+  typename Vec<T>::v8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (T)f[i];
+  return __builtin_bit_cast(u32x4, v);
+}
+
+OMG_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU — diffusers GEGLU uses F.gelu(gate) with the default approximate='none'
+OMG_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 256 zero bytes any lane may source a padded (out-of-image / beyond-K) 16-byte chunk from
+extern __device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
+
+// host side
+void omg_set_error(const char* msg);
+static inline int omg_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { omg_set_error(hipGetErrorString(e)); (void)what; return OMG_ELAUNCH; }
+  return OMG_OK;
+}
+#define OMG_REQUIRE(cond, msg) do { if (!(cond)) { omg_set_error(msg); return OMG_EINVAL; } } while (0)

@@ -1,0 +1,403 @@
+// gemm.hip — MFMA GEMM / implicit-GEMM convolution for gfx950 (CDNA4).
+//
+//   C[M,N] = epi( A[M,K] · W[N,K]^T (+ A2[M,K2] · W2[N,K2]^T) )
+//
+// Both operands are K-contiguous (nn.Linear weights are [N,K]; conv weights are
+// repacked to [Cout][ky][kx][Cin] so that K = (tap, cin) and one 64-wide K slice
+// never straddles a tap).  Activations are NHWC, so the conv A-operand row for
+// output pixel (b,y,x) and tap (dy,dx) is 128 contiguous bytes of the input.
+//
+// Structure (v1): 128x128x64 block tile, 256 threads = 4 wave64 in 2x2, each wave
+// 64x64 = 2x2 tiles of v_mfma_f32_32x32x16.  Tiles are staged global->LDS with
+// LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) into a
+// double-buffered, XOR-swizzled image: the DMA destination is lane-linear, so the
+// swizzle is applied to the per-lane SOURCE chunk and again on the ds_read_b128
+// (cdna guide §5.4 rule 21).  Out-of-image taps and the K tail read a global zero
+// page instead of branching.  The epilogue stages the fp32 accumulators through
+// LDS so that bias/residual loads and the output stores are 16 B per lane on whole
+// 128-byte row segments.
+#include "common.h"
+
+__device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int STAGE_LD = 68;                     // fp32 epilogue staging row stride (64 + 4 pad)
+constexpr int LDS_BYTES_MAIN = 4 * TILE_BYTES;   // A[2] + B[2]
+constexpr int LDS_BYTES_EPI = 4 * 64 * STAGE_LD * 4;
+constexpr int LDS_BYTES = LDS_BYTES_EPI > LDS_BYTES_MAIN ? LDS_BYTES_EPI : LDS_BYTES_MAIN;
+
+struct GemmP {
+  int M, N, K;
+  const char* A; long lda;
+  const char* W; long ldw;
+  const char* A2; long lda2;
+  const char* W2; long ldw2;
+  int K2, a2_col_block;
+  int tile_groups, rows_per_group;   // tile_groups > 1: M tiles never straddle a group
+  const int* group_adapter;
+  long w_adapter_stride, w2_adapter_stride;
+  const char* bias;
+  const char* group_bias; long ldgb;
+  const char* residual; long ldr;
+  int act; float out_scale;
+  char* C; long ldc;
+  // conv geometry (CONV only)
+  int Hin, Win, C1, C2, Hout, Wout, ksize, stride, upsample;
+  const char* X2;
+  int tiles_m, tiles_n;              // tiles_m is per group
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <bool GLDS>
+OMG_DEV void stage16(const char* src, char* lds_wave_base, int lane, u32x4& hold) {
+  if constexpr (GLDS) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+  } else {
+    hold = *(const u32x4*)src;
+  }
+}
+
+template <typename T, bool CONV, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  // ---- tile mapping: XCD-aware bijective remap, then M-fastest within the chunk
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_per_group = p.tiles_m * p.tiles_n;
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  const int tm = t_in % p.tiles_m;
+  const int tn = t_in / p.tiles_m;
+  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
+  const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
+  const int m0 = m_base + tm * BM;
+  const int n0 = tn * BN;
+
+  int adapter = 0;
+  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
+  const bool seg2 = (p.K2 > 0) && (adapter >= 0);
+  if (p.w_adapter_stride != 0 && adapter < 0) return;   // LoRA-down GEMM for a sample without adapter
+  const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
+  const char* W2p = p.W2 + (seg2 ? (long)adapter * p.w2_adapter_stride * 2 : 0);
+  const int a2off = (p.a2_col_block > 0) ? (n0 / p.a2_col_block) * p.K2 : 0;
+
+  const int nk1 = (p.K + BK - 1) / BK;
+  const int nk2 = seg2 ? (p.K2 + BK - 1) / BK : 0;
+  const int nk = nk1 + nk2;
+
+  // ---- per-lane staging coordinates: 4 A rows + 4 W rows per k-tile
+  const int prow = lane >> 3;          // row within the 8-row DMA piece
+  const int ppos = lane & 7;           // 16-B position within the 128-B row
+  int arow[4];                         // global A row (clamped)
+  int wrow[4];                         // global W row (clamped)
+  int cb[4], cy[4], cx[4];             // conv: decoded output pixel
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = w * 32 + i * 8 + prow;
+    int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
+    int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
+    arow[i] = gm; wrow[i] = gn;
+    if constexpr (CONV) {
+      const int hw = p.Hout * p.Wout;
+      const int b = gm / hw; const int rem = gm - b * hw;
+      cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;
+    }
+  }
+  const int Ctot = p.C1 + p.C2;
+  const int cpt = CONV ? Ctot / BK : 1;   // k-tiles per tap
+  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
+  const char* zero = (const char*)omg_zero_page;
+
+  u32x4 hold[8];
+  char* ldsA = smem;
+  char* ldsB = smem + 2 * TILE_BYTES;
+
+  auto issue = [&](int kt, int buf) {
+    const bool s2 = kt >= nk1;
+    const int k0 = (s2 ? kt - nk1 : kt) * BK;
+    const int Kseg = s2 ? p.K2 : p.K;
+    // conv tap decode (wave-uniform)
+    int dy = 0, dx = 0, c0 = k0;
+    const char* xsrc = p.A; int xC = p.C1;
+    if constexpr (CONV) {
+      const int tap = kt / cpt; const int cc = kt - tap * cpt;
+      dy = tap / p.ksize; dx = tap - dy * p.ksize;
+      c0 = cc * BK;
+      if (c0 >= p.C1) { xsrc = p.X2; xC = p.C2; c0 -= p.C1; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = w * 32 + i * 8 + prow;
+      const int c = ppos ^ (r & 7);                    // source chunk for this LDS position
+      const bool kvalid = (k0 + c * 8) < Kseg;
+      // A operand
+      const char* asrc;
+      if constexpr (CONV) {
+        int iy = cy[i] * p.stride + dy - pad;
+        int ix = cx[i] * p.stride + dx - pad;
+        const int Hl = p.upsample ? p.Hin * 2 : p.Hin;
+        const int Wl = p.upsample ? p.Win * 2 : p.Win;
+        const bool ok = (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
+        if (p.upsample) { iy >>= 1; ix >>= 1; }
+        const long pix = ((long)cb[i] * p.Hin + iy) * p.Win + ix;
+        asrc = ok ? xsrc + (pix * xC + c0 + c * 8) * 2 : zero;
+      } else {
+        if (!s2) asrc = kvalid ? p.A + ((long)arow[i] * p.lda + k0 + c * 8) * 2 : zero;
+        else     asrc = kvalid ? p.A2 + ((long)arow[i] * p.lda2 + a2off + k0 + c * 8) * 2 : zero;
+      }
+      stage16<GLDS>(asrc, ldsA + buf * TILE_BYTES + (w * 32 + i * 8) * 128, lane, hold[i]);
+      // W operand
+      const char* wsrc;
+      if (!s2) wsrc = kvalid ? Wp + ((long)wrow[i] * p.ldw + (CONV ? kt * BK : k0) + c * 8) * 2 : zero;
+      else     wsrc = kvalid ? W2p + ((long)wrow[i] * p.ldw2 + k0 + c * 8) * 2 : zero;
+      stage16<GLDS>(wsrc, ldsB + buf * TILE_BYTES + (w * 32 + i * 8) * 128, lane, hold[4 + i]);
+    }
+  };
+  auto commit = [&](int buf) {   // register-staged fallback: write the held chunks
+    if constexpr (!GLDS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int off = (w * 32 + i * 8) * 128 + lane * 16;
+        *(u32x4*)(ldsA + buf * TILE_BYTES + off) = hold[i];
+        *(u32x4*)(ldsB + buf * TILE_BYTES + off) = hold[4 + i];
+      }
+    }
+  };
+
+  const int wm = w >> 1, wn = w & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  using V8 = typename Vec<T>::v8;
+
+  issue(0, 0);
+  commit(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+    const char* a_base = ldsA + buf * TILE_BYTES;
+    const char* b_base = ldsB + buf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      V8 af[2], bf[2];
+      const int kc = ks * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + l31;
+        af[i] = *(const V8*)(a_base + ra * 128 + ((kc ^ (ra & 7)) << 4));
+        const int rb = wn * 64 + i * 32 + l31;
+        bf[i] = *(const V8*)(b_base + rb * 128 + ((kc ^ (rb & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Vec<T>::mfma32(af[i], bf[j], acc[i][j]);
+    }
+    if constexpr (!GLDS) { if (kt + 1 < nk) commit(buf ^ 1); }
+  }
+
+  // ---------------- epilogue: acc -> LDS (fp32) -> coalesced 16-B rows
+  __syncthreads();
+  float* stage = (float*)smem + w * (64 * STAGE_LD);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const int wm0 = m0 + wm * 64;
+  const int wn0 = n0 + wn * 64;
+  if (p.act == OMG_ACT_GEGLU) {
+    // wave tile columns = [32 value | 32 gate]; 4 lanes per row, 16 rows per pass
+    const int ocol0 = (wn0 >> 1);
+    const int sub = lane & 3, rsub = lane >> 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 16 + rsub;
+      const int gm = wm0 + row;
+      const int gc = wn0 + sub * 8;          // packed column of the value half
+      if (gm < m_end && gc < p.N) {
+        float v[8], g[8], bv[8], bg[8];
+        const float* sp = stage + row * STAGE_LD + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
+        if (p.bias) {
+          unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+          unpack8<T>(*(const u32x4*)(p.bias + (long)(gc + 32) * 2), bg);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] += bv[e]; g[e] += bg[e]; }
+        }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
+        *(u32x4*)(p.C + ((long)gm * p.ldc + ocol0 + sub * 8) * 2) = pack8<T>(o);
+      }
+    }
+    return;
+  }
+  {
+    const int sub = lane & 7, rsub = lane >> 3;
+    const int gc = wn0 + sub * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + rsub;
+      const int gm = wm0 + row;
+      if (gm < m_end && gc < p.N) {
+        float v[8];
+        const float* sp = stage + row * STAGE_LD + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
+        if (p.group_bias) {
+          float gb[8];
+          const int g = gm / p.rows_per_group;
+          unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += gb[e];
+        }
+        if (p.act == OMG_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        if (p.residual) {
+          float rv[8];
+          unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
+      }
+    }
+  }
+}
+
+bool g_use_glds = true;
+
+template <typename T, bool CONV>
+int launch(const GemmP& p, hipStream_t s) {
+  const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
+  if (grid <= 0) return OMG_OK;
+  if (g_use_glds) {
+    hipLaunchKernelGGL((gemm_kernel<T, CONV, true>), dim3(grid), dim3(256), LDS_BYTES, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<T, CONV, false>), dim3(grid), dim3(256), LDS_BYTES, s, p);
+  }
+  return omg_check_launch("gemm");
+}
+
+bool g_attr_set = false;
+void ensure_attrs() {
+  if (g_attr_set) return;
+  g_attr_set = true;
+  // > 64 KiB of dynamic LDS needs an explicit opt-in
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<f16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<f16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<f16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<f16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+}
+
+}  // namespace
+
+extern "C" void omg_debug_set_glds(int on) { g_use_glds = on != 0; }
+
+extern "C" int omg_gemm(const omg_gemm_args* a, void* stream) {
+  OMG_REQUIRE(a != nullptr, "omg_gemm: null args");
+  OMG_REQUIRE(a->dtype == OMG_F16 || a->dtype == OMG_BF16, "omg_gemm: dtype");
+  OMG_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, "omg_gemm: shape");
+  if (a->M == 0) return OMG_OK;
+  OMG_REQUIRE(a->K % 8 == 0 && a->N % 8 == 0 && a->K2 % 8 == 0, "omg_gemm: K, K2, N must be multiples of 8");
+  OMG_REQUIRE(a->lda % 8 == 0 && a->ldw % 8 == 0 && a->ldc % 8 == 0, "omg_gemm: leading dims must be multiples of 8");
+  OMG_REQUIRE(a->A && a->W && a->C, "omg_gemm: null operand");
+  OMG_REQUIRE(a->groups >= 1 && (long)a->groups * a->rows_per_group == a->M, "omg_gemm: M != groups*rows_per_group");
+  if (a->K2 > 0) OMG_REQUIRE(a->A2 && a->W2 && a->lda2 % 8 == 0 && a->ldw2 % 8 == 0, "omg_gemm: LoRA segment operands");
+  if (a->act == OMG_ACT_GEGLU) OMG_REQUIRE(a->N % 64 == 0 && !a->residual && !a->group_bias, "omg_gemm: GEGLU needs N % 64 == 0, no residual");
+  if (a->residual) OMG_REQUIRE(a->ldr % 8 == 0, "omg_gemm: ldr");
+  if (a->group_bias) OMG_REQUIRE(a->ldgb % 8 == 0, "omg_gemm: ldgb");
+  ensure_attrs();
+  GemmP p{};
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.A = (const char*)a->A; p.lda = a->lda; p.W = (const char*)a->W; p.ldw = a->ldw;
+  p.A2 = (const char*)a->A2; p.lda2 = a->lda2; p.W2 = (const char*)a->W2; p.ldw2 = a->ldw2;
+  p.K2 = a->K2; p.a2_col_block = a->a2_col_block;
+  const bool per_group = (a->group_adapter != nullptr) && a->groups > 1;
+  p.tile_groups = per_group ? a->groups : 1;
+  p.rows_per_group = a->rows_per_group;
+  p.group_adapter = a->group_adapter;
+  p.w_adapter_stride = a->w_adapter_stride; p.w2_adapter_stride = a->w2_adapter_stride;
+  p.bias = (const char*)a->bias; p.group_bias = (const char*)a->group_bias; p.ldgb = a->ldgb;
+  p.residual = (const char*)a->residual; p.ldr = a->ldr;
+  p.act = a->act; p.out_scale = a->out_scale; p.C = (char*)a->C; p.ldc = a->ldc;
+  const int mrows = per_group ? a->rows_per_group : a->M;
+  p.tiles_m = (mrows + BM - 1) / BM;
+  p.tiles_n = (a->N + BN - 1) / BN;
+  hipStream_t s = (hipStream_t)stream;
+  return a->dtype == OMG_F16 ? launch<f16, false>(p, s) : launch<bf16, false>(p, s);
+}
+
+extern "C" int omg_conv2d(const omg_conv2d_args* a, void* stream) {
+  OMG_REQUIRE(a != nullptr, "omg_conv2d: null args");
+  OMG_REQUIRE(a->dtype == OMG_F16 || a->dtype == OMG_BF16, "omg_conv2d: dtype");
+  OMG_REQUIRE(a->ksize == 1 || a->ksize == 3, "omg_conv2d: ksize must be 1 or 3");
+  OMG_REQUIRE(a->stride == 1 || a->stride == 2, "omg_conv2d: stride must be 1 or 2");
+  OMG_REQUIRE(a->C1 > 0 && a->C1 % 64 == 0 && a->C2 % 64 == 0 && a->C2 >= 0, "omg_conv2d: channels must be multiples of 64");
+  OMG_REQUIRE(a->Cout % 8 == 0, "omg_conv2d: Cout % 8");
+  OMG_REQUIRE(a->X1 && a->W && a->Y && (a->C2 == 0 || a->X2), "omg_conv2d: null operand");
+  OMG_REQUIRE(!(a->upsample && a->stride != 1), "omg_conv2d: upsample with stride");
+  const int Hl = a->upsample ? 2 * a->Hin : a->Hin, Wl = a->upsample ? 2 * a->Win : a->Win;
+  const int pad = a->ksize == 3 ? 1 : 0;
+  OMG_REQUIRE(a->Hout == (Hl + 2 * pad - a->ksize) / a->stride + 1 && a->Wout == (Wl + 2 * pad - a->ksize) / a->stride + 1,
+              "omg_conv2d: output size mismatch");
+  ensure_attrs();
+  GemmP p{};
+  const int Ctot = a->C1 + a->C2;
+  p.M = a->B * a->Hout * a->Wout; p.N = a->Cout; p.K = a->ksize * a->ksize * Ctot;
+  if (p.M == 0) return OMG_OK;
+  p.A = (const char*)a->X1; p.X2 = (const char*)a->X2;
+  p.W = (const char*)a->W; p.ldw = p.K;
+  p.K2 = 0; p.tile_groups = 1; p.rows_per_group = a->Hout * a->Wout;
+  p.bias = (const char*)a->bias; p.group_bias = (const char*)a->group_bias; p.ldgb = a->ldgb;
+  p.residual = (const char*)a->residual; p.ldr = a->Cout;
+  p.act = OMG_ACT_NONE; p.out_scale = a->out_scale; p.C = (char*)a->Y; p.ldc = a->Cout;
+  p.Hin = a->Hin; p.Win = a->Win; p.C1 = a->C1; p.C2 = a->C2; p.Hout = a->Hout; p.Wout = a->Wout;
+  p.ksize = a->ksize; p.stride = a->stride; p.upsample = a->upsample;
+  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  if (a->group_bias) OMG_REQUIRE(a->ldgb % 8 == 0, "omg_conv2d: ldgb");
+  hipStream_t s = (hipStream_t)stream;
+  return a->dtype == OMG_F16 ? launch<f16, true>(p, s) : launch<bf16, true>(p, s);
+}

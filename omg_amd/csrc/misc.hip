@@ -1,0 +1,295 @@
+// misc.hip — boundary convolutions (NCHW latents <-> NHWC features), the time/text
+// conditioning elementwise pieces, and the fused region-fusion + CFG + scheduler step.
+#include "common.h"
+#include <string.h>
+
+static char g_err[256] = "";
+void omg_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
+extern "C" const char* omg_last_error(void) { return g_err; }
+extern "C" int omg_abi_version(void) { return OMG_ABI_VERSION; }
+
+namespace {
+
+// ---------------------------------------------------------------- conv_in
+// out[b,y,x,co] = bias[co] + sum_{ky,kx,ci} w[co][ky][kx][ci] * in[b,ci,y+ky-1,x+kx-1]
+// thread -> (pixel, 8 output channels); weights [Cout][9*Cin] staged in LDS as fp32.
+template <typename T, typename TI>
+__global__ __launch_bounds__(256) void conv_in_kernel(const TI* X, int B, int Cin, int H, int W, const T* Wt, const T* bias,
+                                                       int Cout, char* Y) {
+  extern __shared__ float wl[];   // [Cout][9*Cin]
+  const int K = 9 * Cin;
+  for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = (float)Wt[i];
+  __syncthreads();
+  const int nvec = Cout / 8;
+  const int ppb = 256 / nvec;                 // pixels per block pass
+  const int pl = threadIdx.x / nvec, vec = threadIdx.x - pl * nvec;
+  if (pl >= ppb) return;
+  const long npix = (long)B * H * W;
+  for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
+    const int b = (int)(pix / (H * W)); const int rem = (int)(pix - (long)b * H * W);
+    const int y = rem / W, x = rem - y * W;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? (float)bias[vec * 8 + e] : 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = x + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float v = (float)X[(((long)b * Cin + ci) * H + iy) * W + ix];
+          const int k = (ky * 3 + kx) * Cin + ci;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v * wl[(vec * 8 + e) * K + k];
+        }
+      }
+    }
+    *(u32x4*)(Y + (pix * Cout + vec * 8) * 2) = pack8<T>(acc);
+  }
+}
+
+// --------------------------------------------------------------- conv_out
+// out[b,co,y,x] = bias[co] + sum_{ky,kx,c} w[co][ky][kx][c] * in[b,y+ky-1,x+kx-1,c]
+// one wave per output pixel; lanes stride over (tap, 8-channel vec); Cout <= 8.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_out_kernel(const char* X, int B, int H, int W, int Cin, const char* Wt,
+                                                        const T* bias, int Cout, float* Y) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long npix = (long)B * H * W;
+  const int nvec = Cin / 8;
+  const int K = 9 * Cin;
+  for (long pix = (long)blockIdx.x * 4 + w; pix < npix; pix += (long)gridDim.x * 4) {
+    const int b = (int)(pix / (H * W)); const int rem = (int)(pix - (long)b * H * W);
+    const int y = rem / W, x = rem - y * W;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int i = lane; i < 9 * nvec; i += 64) {
+      const int tap = i / nvec, vec = i - tap * nvec;
+      const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      float f[8];
+      unpack8<T>(*(const u32x4*)(X + ((((long)b * H + iy) * W + ix) * Cin + vec * 8) * 2), f);
+#pragma unroll
+      for (int co = 0; co < 8; ++co) {
+        if (co < Cout) {
+          float wv[8];
+          unpack8<T>(*(const u32x4*)(Wt + ((long)co * K + tap * Cin + vec * 8) * 2), wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[co] += f[e] * wv[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < 8; ++co) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc[co] += __shfl_xor(acc[co], off);
+    }
+    if (lane < Cout) {
+      float v = 0.f;
+#pragma unroll
+      for (int co = 0; co < 8; ++co) if (co == lane) v = acc[co];
+      Y[(((long)b * Cout + lane) * H + y) * W + x] = v + (bias ? (float)bias[lane] : 0.f);
+    }
+  }
+}
+
+// ------------------------------------------------- timestep embedding etc.
+// diffusers get_timestep_embedding(t, dim, flip_sin_to_cos=True, downscale_freq_shift=0):
+// out[i, j] = cos(t_i * f_j) for j < dim/2 ; sin(t_i * f_{j-dim/2}) otherwise; f_j = exp(-ln(10000) * j / (dim/2))
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* t, int n, int dim, T* out, long ldo) {
+  const int i = blockIdx.x;
+  const int half = dim / 2;
+  for (int j = threadIdx.x; j < dim; j += blockDim.x) {
+    const int jj = j < half ? j : j - half;
+    const float freq = expf(-9.210340371976184f * (float)jj / (float)half);
+    const float a = t[i] * freq;
+    out[(long)i * ldo + j] = (T)(j < half ? cosf(a) : sinf(a));
+  }
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* x, T* y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (T)silu_f((float)x[i]);
+}
+
+template <typename T>
+__global__ void copy2d_kernel(const T* src, long lds_, T* dst, long ldd, long rows, long cols) {
+  const long n = rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i - r * cols;
+    dst[r * ldd + c] = src[r * lds_ + c];
+  }
+}
+
+// ------------------------------------------------------ fused step kernel
+struct StepP {
+  int C, H, W, Hm, Wm, n_concepts, fuse;
+  float gs;
+  const float* noise;
+  const float* region[OMG_MAX_CONCEPTS];
+  const float* masks[OMG_MAX_CONCEPTS];
+  const float* coef; int* step_idx; int advance;
+  float* latents; int out_dtype; void* mi_next; float* fused_out;
+};
+
+__global__ __launch_bounds__(256) void step_kernel(StepP p) {
+  const int HW = p.H * p.W;
+  const int n = p.C * HW;                 // elements per sample
+  const int step = *p.step_idx;
+  const float cx = p.coef[step * 4 + 0], ce = p.coef[step * 4 + 1], cin = p.coef[step * 4 + 2];
+  // nearest resize F.interpolate(mode='nearest'): src = floor(dst * in/out)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = i / HW; const int pix = i - c * HW;
+    const int y = pix / p.W, x = pix - y * p.W;
+    float unc0 = p.noise[0 * n + i], unc1 = p.noise[1 * n + i];
+    float cnd0 = p.noise[2 * n + i], cnd1 = p.noise[3 * n + i];
+    if (p.fuse) {
+      const int my = (int)(((long)y * p.Hm) / p.H), mx = (int)(((long)x * p.Wm) / p.W);
+      bool any = false;
+      float add_u = 0.f, add_c = 0.f;
+      for (int k = 0; k < p.n_concepts; ++k) {
+        if (p.masks[k] == nullptr) continue;
+        const bool on = p.masks[k][(long)my * p.Wm + mx] == 1.0f;
+        if (on) {
+          any = true;
+          if (p.region[k]) { add_u += p.region[k][i]; add_c += p.region[k][n + i]; }
+        }
+      }
+      // new = edit * [union == 0] + sum_c region_c * [mask_c == 1]   (overlaps sum)
+      unc1 = (any ? 0.f : unc1) + add_u;
+      cnd1 = (any ? 0.f : cnd1) + add_c;
+      if (p.fused_out) { p.fused_out[i] = unc1; p.fused_out[n + i] = cnd1; }
+    }
+    const float e0 = unc0 + p.gs * (cnd0 - unc0);
+    const float e1 = unc1 + p.gs * (cnd1 - unc1);
+    const float l0 = cx * p.latents[i] + ce * e0;
+    const float l1 = cx * p.latents[n + i] + ce * e1;
+    p.latents[i] = l0; p.latents[n + i] = l1;
+    if (p.mi_next) {
+      const float a0 = l0 * cin, a1 = l1 * cin;
+      if (p.out_dtype == OMG_F16) {
+        f16* o = (f16*)p.mi_next;
+        o[i] = (f16)a0; o[n + i] = (f16)a1; o[2 * n + i] = (f16)a0; o[3 * n + i] = (f16)a1;
+      } else if (p.out_dtype == OMG_BF16) {
+        bf16* o = (bf16*)p.mi_next;
+        o[i] = (bf16)a0; o[n + i] = (bf16)a1; o[2 * n + i] = (bf16)a0; o[3 * n + i] = (bf16)a1;
+      } else {
+        float* o = (float*)p.mi_next;
+        o[i] = a0; o[n + i] = a1; o[2 * n + i] = a0; o[3 * n + i] = a1;
+      }
+    }
+  }
+}
+
+// bump the device step counter after every block of step_kernel has read it: separate 1-thread launch
+__global__ void step_advance_kernel(int* step_idx) { *step_idx = *step_idx + 1; }
+
+__global__ void scale_model_input_kernel(const float* latents, const float* cin, int n, int out_dtype, void* out) {
+  const float c = *cin;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x) {
+    const float v = latents[i] * c;
+    if (out_dtype == OMG_F16) { ((f16*)out)[i] = (f16)v; ((f16*)out)[2 * n + i] = (f16)v; }
+    else if (out_dtype == OMG_BF16) { ((bf16*)out)[i] = (bf16)v; ((bf16*)out)[2 * n + i] = (bf16)v; }
+    else { ((float*)out)[i] = v; ((float*)out)[2 * n + i] = v; }
+  }
+}
+
+}  // namespace
+
+extern "C" int omg_conv_in(int dtype, const void* X, int x_is_f32, int B, int Cin, int H, int W, const void* Wt,
+                           const void* bias, int Cout, void* Y, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_conv_in: dtype");
+  OMG_REQUIRE(X && Wt && Y && Cout % 8 == 0 && Cout / 8 <= 256 && Cin > 0, "omg_conv_in: args");
+  const size_t lds = (size_t)Cout * 9 * Cin * sizeof(float);
+  OMG_REQUIRE(lds <= 64 * 1024, "omg_conv_in: weights exceed 64 KiB of LDS");
+  const long npix = (long)B * H * W;
+  if (npix == 0) return OMG_OK;
+  const int ppb = 256 / (Cout / 8);
+  long blocks = (npix + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMG_F16) {
+    if (x_is_f32) hipLaunchKernelGGL((conv_in_kernel<f16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
+    else hipLaunchKernelGGL((conv_in_kernel<f16, f16>), dim3(blocks), dim3(256), lds, s, (const f16*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
+  } else {
+    if (x_is_f32) hipLaunchKernelGGL((conv_in_kernel<bf16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
+    else hipLaunchKernelGGL((conv_in_kernel<bf16, bf16>), dim3(blocks), dim3(256), lds, s, (const bf16*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
+  }
+  return omg_check_launch("conv_in");
+}
+
+extern "C" int omg_conv_out(int dtype, const void* X, int B, int H, int W, int Cin, const void* Wt, const void* bias,
+                            int Cout, float* Y, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_conv_out: dtype");
+  OMG_REQUIRE(X && Wt && Y && Cin % 8 == 0 && Cout >= 1 && Cout <= 8, "omg_conv_out: args");
+  const long npix = (long)B * H * W;
+  if (npix == 0) return OMG_OK;
+  long blocks = (npix + 3) / 4; if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMG_F16) hipLaunchKernelGGL(conv_out_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Cout, Y);
+  else hipLaunchKernelGGL(conv_out_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
+  return omg_check_launch("conv_out");
+}
+
+extern "C" int omg_timestep_embedding(int dtype, const float* t, int n, int dim, void* out, int64_t ldo, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_timestep_embedding: dtype");
+  OMG_REQUIRE(t && out && dim % 2 == 0 && n >= 0, "omg_timestep_embedding: args");
+  if (n == 0) return OMG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMG_F16) hipLaunchKernelGGL(timestep_embedding_kernel<f16>, dim3(n), dim3(128), 0, s, t, n, dim, (f16*)out, (long)ldo);
+  else hipLaunchKernelGGL(timestep_embedding_kernel<bf16>, dim3(n), dim3(128), 0, s, t, n, dim, (bf16*)out, (long)ldo);
+  return omg_check_launch("timestep_embedding");
+}
+
+extern "C" int omg_silu(int dtype, const void* x, void* y, int64_t n, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_silu: dtype");
+  OMG_REQUIRE(x && y, "omg_silu: null");
+  if (n == 0) return OMG_OK;
+  long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMG_F16) hipLaunchKernelGGL(silu_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const f16*)x, (f16*)y, (long)n);
+  else hipLaunchKernelGGL(silu_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)n);
+  return omg_check_launch("silu");
+}
+
+extern "C" int omg_copy2d(int dtype, const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_copy2d: dtype");
+  OMG_REQUIRE(src && dst, "omg_copy2d: null");
+  const long n = rows * cols;
+  if (n == 0) return OMG_OK;
+  long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  // f16 and bf16 are both 2-byte copies
+  hipLaunchKernelGGL(copy2d_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)src, (long)lds_, (uint16_t*)dst, (long)ldd, (long)rows, (long)cols);
+  return omg_check_launch("copy2d");
+}
+
+extern "C" int omg_fuse_cfg_step(const omg_step_args* a, void* stream) {
+  OMG_REQUIRE(a != nullptr, "omg_fuse_cfg_step: null args");
+  OMG_REQUIRE(a->noise_pred && a->coef && a->step_idx && a->latents, "omg_fuse_cfg_step: null operand");
+  OMG_REQUIRE(a->n_concepts >= 0 && a->n_concepts <= OMG_MAX_CONCEPTS, "omg_fuse_cfg_step: n_concepts");
+  OMG_REQUIRE(a->C > 0 && a->H > 0 && a->W > 0, "omg_fuse_cfg_step: shape");
+  if (a->fuse) OMG_REQUIRE(a->Hm > 0 && a->Wm > 0, "omg_fuse_cfg_step: mask shape");
+  StepP p{};
+  p.C = a->C; p.H = a->H; p.W = a->W; p.Hm = a->Hm; p.Wm = a->Wm; p.n_concepts = a->n_concepts; p.fuse = a->fuse;
+  p.gs = a->guidance_scale; p.noise = a->noise_pred;
+  for (int k = 0; k < OMG_MAX_CONCEPTS; ++k) { p.region[k] = k < a->n_concepts ? a->region_pred[k] : nullptr; p.masks[k] = k < a->n_concepts ? a->masks[k] : nullptr; }
+  p.coef = a->coef; p.step_idx = a->step_idx; p.advance = a->advance;
+  p.latents = a->latents; p.out_dtype = a->out_dtype; p.mi_next = a->model_input_next; p.fused_out = a->fused_noise_out;
+  const int n = a->C * a->H * a->W;
+  int blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(256), 0, s, p);
+  if (a->advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, a->step_idx);
+  return omg_check_launch("fuse_cfg_step");
+}
+
+extern "C" int omg_scale_model_input(int dtype, const float* latents, const float* coef_cin, int n_per_sample, void* out, void* stream) {
+  OMG_REQUIRE(latents && coef_cin && out, "omg_scale_model_input: null");
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16 || dtype == 2, "omg_scale_model_input: dtype");
+  int blocks = (2 * n_per_sample + 255) / 256; if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(scale_model_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, latents, coef_cin, n_per_sample, dtype, out);
+  return omg_check_launch("scale_model_input");
+}

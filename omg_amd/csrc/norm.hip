@@ -1,0 +1,252 @@
+// norm.hip — GroupNorm (NHWC, optional fused SiLU, optional fused channel concat) and
+// LayerNorm for gfx950.  Both are HBM-bound streaming kernels: 16-byte loads per lane,
+// fp32 statistics, deterministic reduction order (no float atomics), so the same
+// input gives bit-identical output on every run.
+//
+// GroupNorm is two launches: `gn_stats` writes per-(sample, pixel-chunk, group) partial
+// (sum, sumsq); `gn_apply` folds the partials in a fixed order (in fp64) into
+// mean/rstd, then streams y = silu?(x*scale + shift).  The second read of x is served
+// by L2 / Infinity Cache for every tensor on the SDXL path (<= 42 MB).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNKS = 64;
+
+struct GnP {
+  const char* X1; int C1; const char* X2; int C2;
+  int B, HW, G, cpg, nvec, tpp, vpt, pr, nchunk, ppc;
+  float eps; const char* gamma; const char* beta; int silu;
+  float* ws; char* Y;
+};
+
+template <typename T>
+OMG_DEV void gn_load(const GnP& p, int b, int pix, int vec, float (&f)[8]) {
+  const int c = vec * 8;
+  const char* src = (c < p.C1) ? p.X1 + (((long)b * p.HW + pix) * p.C1 + c) * 2
+                               : p.X2 + (((long)b * p.HW + pix) * p.C2 + (c - p.C1)) * 2;
+  unpack8<T>(*(const u32x4*)src, f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnP p) {
+  extern __shared__ float lds[];            // [pr][C] sums, then [pr][C] sumsq
+  const int C = p.C1 + p.C2;
+  const int tid = threadIdx.x;
+  const int prow = tid / p.tpp, tv = tid - prow * p.tpp;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int pix0 = chunk * p.ppc;
+  const int pix1 = min(p.HW, pix0 + p.ppc);
+  float s[2][8], q[2][8];
+#pragma unroll
+  for (int v = 0; v < 2; ++v)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[v][e] = 0.f; q[v][e] = 0.f; }
+  if (prow < p.pr) {
+    for (int pix = pix0 + prow; pix < pix1; pix += p.pr) {
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int vec = tv + v * p.tpp;
+        if (v < p.vpt && vec < p.nvec) {
+          float f[8];
+          gn_load<T>(p, b, pix, vec, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[v][e] += f[e]; q[v][e] += f[e] * f[e]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int vec = tv + v * p.tpp;
+      if (v < p.vpt && vec < p.nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          lds[prow * C + vec * 8 + e] = s[v][e];
+          lds[(p.pr + prow) * C + vec * 8 + e] = q[v][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < p.G) {
+    float ss = 0.f, qq = 0.f;
+    for (int r = 0; r < p.pr; ++r)
+      for (int c = tid * p.cpg; c < (tid + 1) * p.cpg; ++c) { ss += lds[r * C + c]; qq += lds[(p.pr + r) * C + c]; }
+    float* out = p.ws + (((long)b * GN_MAX_CHUNKS + chunk) * p.G + tid) * 2;
+    out[0] = ss; out[1] = qq;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int C = p.C1 + p.C2;
+  if (tid < p.G) {
+    double ss = 0.0, qq = 0.0;
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+      const float* in = p.ws + (((long)b * GN_MAX_CHUNKS + ch) * p.G + tid) * 2;
+      ss += (double)in[0]; qq += (double)in[1];
+    }
+    const double n = (double)p.HW * p.cpg;
+    const double mean = ss / n;
+    double var = qq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_s[tid] = (float)mean;
+    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const int prow = tid / p.tpp, tv = tid - prow * p.tpp;
+  if (prow >= p.pr) return;
+  float sc[2][8], sh[2][8];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int vec = tv + v * p.tpp;
+    if (v < p.vpt && vec < p.nvec) {
+      float ga[8], be[8];
+      unpack8<T>(*(const u32x4*)(p.gamma + (long)vec * 16), ga);
+      unpack8<T>(*(const u32x4*)(p.beta + (long)vec * 16), be);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (vec * 8 + e) / p.cpg;
+        const float a = rstd_s[g] * ga[e];
+        sc[v][e] = a; sh[v][e] = be[e] - mean_s[g] * a;
+      }
+    }
+  }
+  const int pix0 = chunk * p.ppc;
+  const int pix1 = min(p.HW, pix0 + p.ppc);
+  for (int pix = pix0 + prow; pix < pix1; pix += p.pr) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int vec = tv + v * p.tpp;
+      if (v < p.vpt && vec < p.nvec) {
+        float f[8];
+        gn_load<T>(p, b, pix, vec, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float y = f[e] * sc[v][e] + sh[v][e];
+          if (p.silu) y = silu_f(y);
+          f[e] = y;
+        }
+        *(u32x4*)(p.Y + (((long)b * p.HW + pix) * C + vec * 8) * 2) = pack8<T>(f);
+      }
+    }
+  }
+}
+
+// LayerNorm: one wave per row, row held in registers, exact two-pass variance.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const char* X, long ldx, int M, int C, float eps, const char* gamma,
+                                                 const char* beta, char* Y, long ldy) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= M) return;
+  const int nvec = C >> 3;
+  float x[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int vec = lane + v * 64;
+    if (vec < nvec) {
+      unpack8<T>(*(const u32x4*)(X + ((long)row * ldx + vec * 8) * 2), x[v]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[v][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[v][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int vec = lane + v * 64;
+    if (vec < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = x[v][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int vec = lane + v * 64;
+    if (vec < nvec) {
+      float ga[8], be[8], y[8];
+      unpack8<T>(*(const u32x4*)(gamma + (long)vec * 16), ga);
+      unpack8<T>(*(const u32x4*)(beta + (long)vec * 16), be);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (x[v][e] - mean) * rstd * ga[e] + be[e];
+      *(u32x4*)(Y + ((long)row * ldy + vec * 8) * 2) = pack8<T>(y);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t omg_groupnorm_ws_floats(int B, int groups, int HW) {
+  (void)HW;
+  return (int64_t)B * GN_MAX_CHUNKS * groups * 2;
+}
+
+extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
+                             float eps, const void* gamma, const void* beta, int silu, float* workspace, void* Y,
+                             void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_groupnorm: dtype");
+  OMG_REQUIRE(X1 && gamma && beta && workspace && Y && (C2 == 0 || X2), "omg_groupnorm: null operand");
+  const int C = C1 + C2;
+  OMG_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && groups <= 64 && groups > 0, "omg_groupnorm: channels/groups");
+  OMG_REQUIRE(C / 8 <= 512, "omg_groupnorm: C <= 4096");
+  if (B == 0 || HW == 0) return OMG_OK;
+  GnP p{};
+  p.X1 = (const char*)X1; p.C1 = C1; p.X2 = (const char*)X2; p.C2 = C2;
+  p.B = B; p.HW = HW; p.G = groups; p.cpg = C / groups; p.nvec = C / 8;
+  p.vpt = p.nvec <= 256 ? 1 : 2;
+  p.tpp = p.vpt == 1 ? p.nvec : (p.nvec + 1) / 2;
+  p.pr = 256 / p.tpp;
+  long elems = (long)HW * C;
+  int nchunk = (int)((elems + 16383) / 16384);
+  if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
+  if (nchunk > HW) nchunk = HW;
+  if (nchunk < 1) nchunk = 1;
+  p.ppc = (HW + nchunk - 1) / nchunk;
+  nchunk = (HW + p.ppc - 1) / p.ppc;
+  p.nchunk = nchunk;
+  p.eps = eps; p.gamma = (const char*)gamma; p.beta = (const char*)beta; p.silu = silu;
+  p.ws = workspace; p.Y = (char*)Y;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(nchunk, B);
+  const size_t lds = (size_t)2 * p.pr * C * sizeof(float);
+  if (dtype == OMG_F16) {
+    hipLaunchKernelGGL(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(gn_apply_kernel<f16>, grid, dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(256), 0, s, p);
+  }
+  return omg_check_launch("groupnorm");
+}
+
+extern "C" int omg_layernorm(int dtype, const void* X, int64_t ldx, int M, int C, float eps, const void* gamma,
+                             const void* beta, void* Y, int64_t ldy, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_layernorm: dtype");
+  OMG_REQUIRE(X && gamma && beta && Y, "omg_layernorm: null operand");
+  OMG_REQUIRE(C % 8 == 0 && C <= 2048 && ldx % 8 == 0 && ldy % 8 == 0, "omg_layernorm: C % 8, C <= 2048");
+  if (M == 0) return OMG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((M + 3) / 4);
+  const int nv = (C / 8 + 63) / 64;
+#define LN_LAUNCH(TT, NVV) hipLaunchKernelGGL((ln_kernel<TT, NVV>), grid, dim3(256), 0, s, (const char*)X, (long)ldx, M, C, eps, (const char*)gamma, (const char*)beta, (char*)Y, (long)ldy)
+  if (dtype == OMG_F16) {
+    switch (nv) { case 1: LN_LAUNCH(f16, 1); break; case 2: LN_LAUNCH(f16, 2); break; case 3: LN_LAUNCH(f16, 3); break; default: LN_LAUNCH(f16, 4); }
+  } else {
+    switch (nv) { case 1: LN_LAUNCH(bf16, 1); break; case 2: LN_LAUNCH(bf16, 2); break; case 3: LN_LAUNCH(bf16, 3); break; default: LN_LAUNCH(bf16, 4); }
+  }
+#undef LN_LAUNCH
+  return omg_check_launch("layernorm");
+}

@@ -1,0 +1,387 @@
+"""Thin torch-tensor wrappers over the C ABI (``include/omg_hip.h``).
+
+PyTorch here is plumbing only: it owns device memory (``torch.empty``), the current
+HIP stream and nothing else — every arithmetic op below is a hand-written gfx950
+kernel in ``omg_amd/csrc``.  All wrappers launch on ``torch.cuda.current_stream()``
+so they are captured by ``torch.cuda.graph`` (hipGraph) like any torch op.
+Tensors must live on a ROCm device; a CPU tensor raises (no fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float16: L.OMG_F16, torch.bfloat16: L.OMG_BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise L.OmgHipError(f"unsupported dtype {t.dtype}; use float16 or bfloat16") from None
+
+
+def _dev(t: torch.Tensor) -> None:
+    if not t.is_cuda:
+        raise L.OmgHipError("omg_amd ops need tensors on the MI355X (cuda/hip device); there is no CPU fallback")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class LoraSpec:
+    """Second K-segment of a GEMM: ``C += A2 @ W2[adapter]^T`` (PEFT ``s * B(A(x))``)."""
+
+    __slots__ = ("a2", "w2", "group_adapter", "a2_col_block")
+
+    def __init__(self, a2: torch.Tensor, w2: torch.Tensor, group_adapter: Optional[torch.Tensor] = None,
+                 a2_col_block: int = 0):
+        self.a2, self.w2, self.group_adapter, self.a2_col_block = a2, w2, group_adapter, a2_col_block
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None,
+         out_scale: float = 1.0, group_bias: Optional[torch.Tensor] = None, groups: int = 1,
+         lora: Optional[LoraSpec] = None, w_group_adapter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[M, N_out] = epi(a[M,K] @ w[N,K]^T)``; see ``omg_gemm`` in include/omg_hip.h.
+
+    ``w`` may be 3-D ``[n_adapters, N, K]`` together with ``w_group_adapter`` (int32 device
+    tensor, one adapter id per group) — the LoRA-down projection of a batch whose samples
+    use different adapters.
+    """
+    _dev(a)
+    M, K = a.shape
+    assert a.stride(1) == 1
+    if w.dim() == 3:
+        N = w.shape[1]
+        w_stride = w.stride(0)
+        ldw = w.stride(1)
+    else:
+        N = w.shape[0]
+        w_stride = 0
+        ldw = w.stride(0)
+    assert w.shape[-1] == K and w.stride(-1) == 1
+    n_out = N // 2 if act == L.ACT_GEGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=a.dtype, device=a.device)
+    assert out.stride(1) == 1 and out.shape[0] == M and out.shape[1] == n_out
+    args = L.GemmArgs()
+    args.dtype = _dt(a)
+    args.M, args.N, args.K = M, N, K
+    args.A, args.lda = a.data_ptr(), a.stride(0)
+    args.W, args.ldw = w.data_ptr(), ldw
+    args.groups = groups
+    args.rows_per_group = M // groups
+    adapter = w_group_adapter
+    if lora is not None:
+        a2, w2 = lora.a2, lora.w2
+        args.A2, args.lda2 = a2.data_ptr(), a2.stride(0)
+        args.K2 = w2.shape[-1]
+        args.W2 = w2.data_ptr()
+        if w2.dim() == 3:
+            args.ldw2, args.w2_adapter_stride = w2.stride(1), w2.stride(0)
+        else:
+            args.ldw2, args.w2_adapter_stride = w2.stride(0), 0
+        args.a2_col_block = lora.a2_col_block
+        if lora.group_adapter is not None:
+            adapter = lora.group_adapter
+    args.group_adapter = _p(adapter)
+    args.w_adapter_stride = w_stride
+    args.bias = _p(bias)
+    if group_bias is not None:
+        args.group_bias, args.ldgb = group_bias.data_ptr(), group_bias.stride(0)
+    if residual is not None:
+        assert residual.stride(1) == 1
+        args.residual, args.ldr = residual.data_ptr(), residual.stride(0)
+    args.act = act
+    args.out_scale = out_scale
+    args.C, args.ldc = out.data_ptr(), out.stride(0)
+    L.check(L.lib().omg_gemm(C.byref(args), _stream()), "omg_gemm")
+    return out
+
+
+def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, upsample: bool = False,
+           x2: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+           group_bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           out_scale: float = 1.0) -> torch.Tensor:
+    """NHWC implicit-GEMM conv; ``w`` is ``[Cout, ksize*ksize*(C1+C2)]`` (see pack_conv_weight)."""
+    _dev(x1)
+    B, Hin, Win, C1 = x1.shape
+    assert x1.is_contiguous()
+    C2 = 0
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.shape[:3] == x1.shape[:3]
+        C2 = x2.shape[3]
+    Cout = w.shape[0]
+    assert w.is_contiguous() and w.shape[1] == ksize * ksize * (C1 + C2)
+    Hl, Wl = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
+    pad = 1 if ksize == 3 else 0
+    Hout = (Hl + 2 * pad - ksize) // stride + 1
+    Wout = (Wl + 2 * pad - ksize) // stride + 1
+    y = torch.empty((B, Hout, Wout, Cout), dtype=x1.dtype, device=x1.device)
+    a = L.Conv2dArgs()
+    a.dtype = _dt(x1)
+    a.B, a.Hin, a.Win, a.C1, a.C2 = B, Hin, Win, C1, C2
+    a.Hout, a.Wout, a.Cout = Hout, Wout, Cout
+    a.ksize, a.stride, a.upsample = ksize, stride, int(upsample)
+    a.X1, a.X2, a.W, a.bias = x1.data_ptr(), _p(x2), w.data_ptr(), _p(bias)
+    if group_bias is not None:
+        a.group_bias, a.ldgb = group_bias.data_ptr(), group_bias.stride(0)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == y.shape
+        a.residual = residual.data_ptr()
+    a.out_scale = out_scale
+    a.Y = y.data_ptr()
+    L.check(L.lib().omg_conv2d(C.byref(a), _stream()), "omg_conv2d")
+    return y
+
+
+def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None) -> torch.Tensor:
+    """``v``: (B, Nkv, >=heads*64) view with unit inner stride -> Vt (B, heads, 64, Nkv_pad)."""
+    _dev(v)
+    B, Nkv = v.shape[0], v.shape[1]
+    if nkv_pad is None:
+        nkv_pad = (Nkv + 63) // 64 * 64
+    vt = torch.empty((B, heads, 64, nkv_pad), dtype=v.dtype, device=v.device)
+    L.check(L.lib().omg_transpose_v(_dt(v), v.data_ptr(), v.stride(1), v.stride(0), B, heads, Nkv, nkv_pad,
+                                    vt.data_ptr(), _stream()), "omg_transpose_v")
+    return vt
+
+
+def _attn_args(q, k, vt, heads, nkv, scale, qk_src, out, accumulate, out_scale) -> L.AttnArgs:
+    a = L.AttnArgs()
+    a.dtype = _dt(q)
+    a.B, a.heads, a.Nq, a.Nkv = q.shape[0], heads, q.shape[1], nkv
+    a.Q, a.ldq, a.q_bstride = q.data_ptr(), q.stride(1), q.stride(0)
+    a.K, a.ldk, a.k_bstride = k.data_ptr(), k.stride(1), k.stride(0)
+    if vt is not None:
+        a.Vt, a.Nkv_pad = vt.data_ptr(), vt.shape[3]
+    a.qk_src = _p(qk_src)
+    a.scale = scale
+    a.accumulate = int(accumulate)
+    a.out_scale = out_scale
+    if out is not None:
+        a.O, a.ldo, a.o_bstride = out.data_ptr(), out.stride(1), out.stride(0)
+    return a
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: float, *,
+              qk_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+              accumulate: bool = False, out_scale: float = 1.0) -> torch.Tensor:
+    """Fused attention.  q: (B,Nq,>=heads*64) view, k: (B,Nkv,>=heads*64) view, vt from transpose_v.
+
+    ``qk_src`` (int32 device tensor [B]) implements the controller's probability replacement:
+    sample b uses Q,K of sample qk_src[b] and its own V.
+    """
+    _dev(q)
+    assert q.stride(2) == 1 and k.stride(2) == 1
+    B, Nq = q.shape[0], q.shape[1]
+    if out is None:
+        out = torch.empty((B, Nq, heads * 64), dtype=q.dtype, device=q.device)
+    a = _attn_args(q, k, vt, heads, k.shape[1], scale, qk_src, out, accumulate, out_scale)
+    L.check(L.lib().omg_attn_fwd(C.byref(a), _stream()), "omg_attn_fwd")
+    return out
+
+
+def attn_probs(q: torch.Tensor, k: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """Materialised softmax probabilities (B*heads, Nq, Nkv) — protocol mode only."""
+    _dev(q)
+    B, Nq, Nkv = q.shape[0], q.shape[1], k.shape[1]
+    p = torch.empty((B * heads, Nq, Nkv), dtype=q.dtype, device=q.device)
+    a = _attn_args(q, k, None, heads, Nkv, scale, None, None, False, 1.0)
+    L.check(L.lib().omg_attn_probs(C.byref(a), p.data_ptr(), _stream()), "omg_attn_probs")
+    return p
+
+
+def attn_apply_probs(p: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+    _dev(p)
+    B, Nkv = v.shape[0], v.shape[1]
+    Nq = p.shape[1]
+    assert p.is_contiguous() and p.shape[0] == B * heads and p.shape[2] == Nkv
+    out = torch.empty((B, Nq, heads * 64), dtype=p.dtype, device=p.device)
+    L.check(L.lib().omg_attn_apply_probs(_dt(p), p.data_ptr(), v.data_ptr(), v.stride(1), v.stride(0), B, heads, Nq,
+                                         Nkv, out.data_ptr(), out.stride(1), out.stride(0), _stream()),
+            "omg_attn_apply_probs")
+    return out
+
+
+_gn_ws = {}
+
+
+def _gn_workspace(device, B: int, groups: int, HW: int) -> torch.Tensor:
+    n = int(L.lib().omg_groupnorm_ws_floats(B, groups, HW))
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _gn_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device)
+        _gn_ws[key] = ws
+    return ws
+
+
+def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
+              silu: bool = False, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC GroupNorm (+SiLU) of the channel-concat [x1 | x2]; x: (B, H, W, C) or (B, HW, C)."""
+    _dev(x1)
+    assert x1.is_contiguous()
+    B = x1.shape[0]
+    C1 = x1.shape[-1]
+    HW = x1.numel() // (B * C1)
+    C2 = 0
+    if x2 is not None:
+        assert x2.is_contiguous()
+        C2 = x2.shape[-1]
+    y = torch.empty(x1.shape[:-1] + (C1 + C2,), dtype=x1.dtype, device=x1.device)
+    ws = _gn_workspace(x1.device, B, groups, HW)
+    L.check(L.lib().omg_groupnorm(_dt(x1), x1.data_ptr(), C1, _p(x2), C2, B, HW, groups, eps, gamma.data_ptr(),
+                                  beta.data_ptr(), int(silu), ws.data_ptr(), y.data_ptr(), _stream()), "omg_groupnorm")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    _dev(x)
+    Cc = x.shape[-1]
+    x2 = x.reshape(-1, Cc)
+    assert x2.stride(1) == 1
+    y = torch.empty((x2.shape[0], Cc), dtype=x.dtype, device=x.device)
+    L.check(L.lib().omg_layernorm(_dt(x), x2.data_ptr(), x2.stride(0), x2.shape[0], Cc, eps, gamma.data_ptr(),
+                                  beta.data_ptr(), y.data_ptr(), y.stride(0), _stream()), "omg_layernorm")
+    return y.view(x.shape)
+
+
+def conv_in(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """NCHW latents (fp32 or `dtype`) -> NHWC features in `dtype`; w: [Cout][3][3][Cin] in `dtype`."""
+    _dev(x_nchw)
+    assert x_nchw.is_contiguous()
+    B, Cin, H, W = x_nchw.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, H, W, Cout), dtype=dtype, device=x_nchw.device)
+    is_f32 = x_nchw.dtype == torch.float32
+    assert is_f32 or x_nchw.dtype == dtype
+    L.check(L.lib().omg_conv_in(_DT[dtype], x_nchw.data_ptr(), int(is_f32), B, Cin, H, W, w.data_ptr(), _p(bias), Cout,
+                                y.data_ptr(), _stream()), "omg_conv_in")
+    return y
+
+
+def conv_out(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC features -> NCHW fp32; w: [Cout][3][3][Cin]."""
+    _dev(x_nhwc)
+    assert x_nhwc.is_contiguous()
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_nhwc.device)
+    assert out.is_contiguous() and out.dtype == torch.float32
+    L.check(L.lib().omg_conv_out(_dt(x_nhwc), x_nhwc.data_ptr(), B, H, W, Cin, w.data_ptr(), _p(bias), Cout,
+                                 out.data_ptr(), _stream()), "omg_conv_out")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """t: fp32 device tensor [n] -> [n, dim] (cos | sin), written into `out` (may be a column slice)."""
+    _dev(t)
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    n = t.numel()
+    if out is None:
+        out = torch.empty((n, dim), dtype=dtype, device=t.device)
+    assert out.stride(1) == 1
+    L.check(L.lib().omg_timestep_embedding(_DT[dtype], t.data_ptr(), n, dim, out.data_ptr(), out.stride(0), _stream()),
+            "omg_timestep_embedding")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    L.check(L.lib().omg_silu(_dt(x), x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "omg_silu")
+    return y
+
+
+def copy2d(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[r, :cols] = src[r, :cols] for 2-D views with unit inner stride."""
+    _dev(src)
+    assert src.dim() == 2 and dst.dim() == 2 and src.shape == dst.shape and src.stride(1) == 1 and dst.stride(1) == 1
+    L.check(L.lib().omg_copy2d(_dt(src), src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0],
+                               src.shape[1], _stream()), "omg_copy2d")
+
+
+def fuse_cfg_step(noise_pred: torch.Tensor, latents: torch.Tensor, coef: torch.Tensor, step_idx: torch.Tensor, *,
+                  guidance_scale: float, fuse: bool = False, region_preds: Sequence[Optional[torch.Tensor]] = (),
+                  masks: Sequence[Optional[torch.Tensor]] = (), model_input_next: Optional[torch.Tensor] = None,
+                  advance: bool = True, fused_noise_out: Optional[torch.Tensor] = None) -> None:
+    """Region fusion + CFG + scheduler step + next model input (see omg_fuse_cfg_step)."""
+    _dev(noise_pred)
+    assert noise_pred.dtype == torch.float32 and noise_pred.is_contiguous() and noise_pred.shape[0] == 4
+    assert latents.dtype == torch.float32 and latents.is_contiguous() and latents.shape[0] == 2
+    assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.shape[-1] == 4
+    assert step_idx.dtype == torch.int32
+    _, Cc, H, W = noise_pred.shape
+    a = L.StepArgs()
+    a.C, a.H, a.W = Cc, H, W
+    a.n_concepts = len(masks)
+    assert len(region_preds) == len(masks) <= L.MAX_CONCEPTS
+    a.fuse = int(fuse)
+    a.guidance_scale = guidance_scale
+    a.noise_pred = noise_pred.data_ptr()
+    hm = wm = 0
+    for i, (r, m) in enumerate(zip(region_preds, masks)):
+        if r is not None:
+            assert r.dtype == torch.float32 and r.is_contiguous() and r.shape == (2, Cc, H, W)
+            a.region_pred[i] = r.data_ptr()
+        if m is not None:
+            assert m.dtype == torch.float32 and m.is_contiguous() and m.dim() == 2
+            if hm:
+                assert (hm, wm) == tuple(m.shape), "all masks must share one resolution"
+            hm, wm = m.shape
+            a.masks[i] = m.data_ptr()
+    a.Hm, a.Wm = (hm, wm) if hm else (H, W)
+    a.coef, a.step_idx, a.advance = coef.data_ptr(), step_idx.data_ptr(), int(advance)
+    a.latents = latents.data_ptr()
+    if model_input_next is not None:
+        assert model_input_next.is_contiguous() and model_input_next.shape == (4, Cc, H, W)
+        a.model_input_next = model_input_next.data_ptr()
+        a.out_dtype = L.OMG_F32 if model_input_next.dtype == torch.float32 else _dt(model_input_next)
+    if fused_noise_out is not None:
+        assert fused_noise_out.dtype == torch.float32 and fused_noise_out.is_contiguous()
+        a.fused_noise_out = fused_noise_out.data_ptr()
+    L.check(L.lib().omg_fuse_cfg_step(C.byref(a), _stream()), "omg_fuse_cfg_step")
+
+
+def scale_model_input(latents: torch.Tensor, coef_cin: torch.Tensor, out: torch.Tensor) -> None:
+    """out[4,C,H,W] = cin * cat([latents]*2); coef_cin: 1-element fp32 device tensor."""
+    _dev(latents)
+    assert latents.dtype == torch.float32 and latents.is_contiguous() and out.is_contiguous()
+    n = latents[0].numel()
+    dt = L.OMG_F32 if out.dtype == torch.float32 else _dt(out)
+    L.check(L.lib().omg_scale_model_input(dt, latents.data_ptr(), coef_cin.data_ptr(), n, out.data_ptr(), _stream()),
+            "omg_scale_model_input")
+
+
+# ------------------------------------------------------------------ host-side weight packing
+def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """diffusers conv weight [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin] (K = (tap, cin)); pure layout."""
+    co, ci, kh, kw = w_oihw.shape
+    return w_oihw.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+
+
+def geglu_row_perm(n_total: int) -> torch.Tensor:
+    """Row permutation that interleaves GEGLU value/gate rows in blocks of 32 (see gemm.hip epilogue).
+
+    packed row p: block = p // 64, j = p % 64; j < 32 -> value row block*32 + j,
+    else gate row n_total/2 + block*32 + (j - 32).
+    """
+    nh = n_total // 2
+    assert nh % 32 == 0
+    p = torch.arange(n_total)
+    blk, j = p // 64, p % 64
+    return torch.where(j < 32, blk * 32 + j, nh + blk * 32 + (j - 32))

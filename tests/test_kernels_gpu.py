@@ -1,0 +1,282 @@
+"""Kernel-level parity (-m gpu): every C-ABI kernel vs a plain fp32 torch-CPU reference of the
+same op, on the same (dtype-rounded) inputs, at the shapes of SURVEY.md §8(a) plus ragged edges."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from omg_amd import _lib as L
+from omg_amd import ops
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: dict(rtol=2e-3, atol=2e-3), torch.bfloat16: dict(rtol=1.6e-2, atol=1.6e-2)}
+
+
+def rnd(*shape, dtype, dev, scale=1.0, seed=None):
+    g = torch.Generator().manual_seed(seed if seed is not None else sum(shape) + 17)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def close(out, ref, dtype, scale=1.0):
+    t = TOL[dtype]
+    torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=t["rtol"], atol=t["atol"] * scale)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 136, 72), (77 * 4, 640, 2048), (4, 1280, 320), (1024, 64, 640), (2048, 1280, 1280)])
+def test_gemm_plain(dev, dtype, glds, M, N, K):
+    L.lib().omg_debug_set_glds(glds)
+    try:
+        a = rnd(M, K, dtype=dtype, dev=dev)
+        w = rnd(N, K, dtype=dtype, dev=dev, scale=K ** -0.5)
+        bias = rnd(N, dtype=dtype, dev=dev)
+        res = rnd(M, N, dtype=dtype, dev=dev)
+        out = ops.gemm(a, w, bias=bias, residual=res, out_scale=0.5)
+        ref = (a.float().cpu() @ w.float().cpu().T + bias.float().cpu()) * 0.5 + res.float().cpu()
+        close(out, ref, dtype)
+        out2 = ops.gemm(a, w, act=L.ACT_SILU)
+        close(out2, F.silu(a.float().cpu() @ w.float().cpu().T), dtype)
+    finally:
+        L.lib().omg_debug_set_glds(1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(dev, dtype):
+    """A = I with an asymmetric W catches a transposed C-write (cdna guide G9)."""
+    n = 128
+    a = torch.eye(n, dtype=dtype, device=dev)
+    w = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 97 / 97.0).to(dtype).to(dev)
+    out = ops.gemm(a, w)
+    close(out, w.float().cpu().T, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_geglu(dev, dtype):
+    M, C = 300, 640
+    N = 8 * C
+    a = rnd(M, C, dtype=dtype, dev=dev)
+    w = rnd(N, C, dtype=dtype, dev=dev, scale=C ** -0.5)
+    b = rnd(N, dtype=dtype, dev=dev)
+    perm = ops.geglu_row_perm(N).to(dev)
+    out = ops.gemm(a, w[perm].contiguous(), bias=b[perm].contiguous(), act=L.ACT_GEGLU)
+    h = a.float().cpu() @ w.float().cpu().T + b.float().cpu()
+    val, gate = h.chunk(2, dim=-1)
+    close(out, val * F.gelu(gate), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_group_bias_and_strided(dev, dtype):
+    B, rows, N, K = 3, 100, 320, 192
+    big = rnd(B * rows, K + 64, dtype=dtype, dev=dev)
+    a = big[:, 32:32 + K]  # strided view with unit inner stride (8-element aligned offset)
+    w = rnd(N, K, dtype=dtype, dev=dev, scale=K ** -0.5)
+    gb = rnd(B, N, dtype=dtype, dev=dev)
+    out = ops.gemm(a, w, group_bias=gb, groups=B)
+    ref = a.float().cpu() @ w.float().cpu().T + gb.float().cpu().repeat_interleave(rows, 0)
+    close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows", [256, 77])
+def test_gemm_lora_segment(dev, dtype, rows):
+    """base(x) + s*B_c(A_c(x)) with a different adapter per sample (and one sample without)."""
+    B, N, K, r = 4, 640, 640, 64
+    x = rnd(B * rows, K, dtype=dtype, dev=dev)
+    w = rnd(N, K, dtype=dtype, dev=dev, scale=K ** -0.5)
+    down = rnd(2, r, K, dtype=dtype, dev=dev, scale=K ** -0.5)   # A_c
+    up = rnd(2, N, r, dtype=dtype, dev=dev, scale=0.1)           # s * B_c
+    adapter = torch.tensor([-1, 0, 1, 0], dtype=torch.int32, device=dev)
+    t = torch.zeros(B * rows, r, dtype=dtype, device=dev)
+    ops.gemm(x, down, out=t, groups=B, w_group_adapter=adapter)
+    out = ops.gemm(x, w, groups=B, lora=ops.LoraSpec(t, up, adapter))
+    xf, wf = x.float().cpu(), w.float().cpu()
+    ref = xf @ wf.T
+    for b, ad in enumerate(adapter.tolist()):
+        if ad >= 0:
+            sl = slice(b * rows, (b + 1) * rows)
+            tt = (xf[sl] @ down[ad].float().cpu().T).to(dtype).float()
+            ref[sl] += tt @ up[ad].float().cpu().T
+    close(out, ref, dtype)
+
+
+# ------------------------------------------------------------------ conv
+def conv_ref(x_nhwc, w_oihw, stride, upsample, bias=None, gb=None, res=None, scale=1.0):
+    x = x_nhwc.float().cpu().permute(0, 3, 1, 2)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    k = w_oihw.shape[-1]
+    y = F.conv2d(x, w_oihw.float().cpu(), None if bias is None else bias.float().cpu(), stride=stride, padding=k // 2)
+    if gb is not None:
+        y = y + gb.float().cpu()[:, :, None, None]
+    y = y * scale
+    if res is not None:
+        y = y + res.float().cpu().permute(0, 3, 1, 2)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=16, W=16, C1=64, C2=0, Co=64, k=3, s=1, up=False),
+    dict(B=2, H=17, W=13, C1=128, C2=64, Co=72, k=3, s=1, up=False),
+    dict(B=1, H=16, W=16, C1=64, C2=0, Co=128, k=3, s=2, up=False),
+    dict(B=2, H=8, W=8, C1=64, C2=0, Co=64, k=3, s=1, up=True),
+    dict(B=2, H=12, W=12, C1=128, C2=0, Co=64, k=1, s=1, up=False),
+    dict(B=1, H=32, W=32, C1=320, C2=320, Co=320, k=3, s=1, up=False),
+])
+def test_conv2d(dev, dtype, case):
+    c = case
+    Ct = c["C1"] + c["C2"]
+    x1 = rnd(c["B"], c["H"], c["W"], c["C1"], dtype=dtype, dev=dev)
+    x2 = rnd(c["B"], c["H"], c["W"], c["C2"], dtype=dtype, dev=dev, seed=5) if c["C2"] else None
+    w = rnd(c["Co"], Ct, c["k"], c["k"], dtype=dtype, dev=dev, scale=(Ct * c["k"] ** 2) ** -0.5)
+    bias = rnd(c["Co"], dtype=dtype, dev=dev)
+    gb = rnd(c["B"], c["Co"], dtype=dtype, dev=dev, seed=9)
+    xin = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+    y0 = conv_ref(xin, w, c["s"], c["up"], bias, gb)
+    res = rnd(*y0.shape, dtype=dtype, dev=dev, seed=11)
+    y = ops.conv2d(x1, ops.pack_conv_weight(w), c["k"], stride=c["s"], upsample=c["up"], x2=x2, bias=bias,
+                   group_bias=gb, residual=res)
+    close(y, y0 + res.float().cpu(), dtype)
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(q, k, v, heads, scale, qk_src=None):
+    B, Nq, _ = q.shape
+    qf, kf, vf = (t.float().cpu() for t in (q, k, v))
+    if qk_src is not None:
+        qf, kf = qf[qk_src], kf[qk_src]
+    def split(t):
+        return t.reshape(t.shape[0], t.shape[1], heads, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(split(qf) @ split(kf).transpose(-1, -2) * scale, dim=-1)
+    return (p @ split(vf)).permute(0, 2, 1, 3).reshape(B, Nq, heads * 64)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 2, 256, 256), (4, 10, 1024, 1024), (2, 3, 1000, 77), (4, 5, 200, 93), (1, 1, 128, 16), (2, 2, 4096, 4096)])
+def test_attention(dev, dtype, B, heads, Nq, Nkv):
+    Cc = heads * 64
+    qkv = rnd(B, Nq, 3 * Cc, dtype=dtype, dev=dev, scale=1.5)   # fused projection buffer (strided views)
+    q = qkv[:, :, :Cc]
+    if Nkv == Nq:
+        k, v = qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:]
+    else:
+        kv = rnd(B, Nkv, 2 * Cc, dtype=dtype, dev=dev, scale=1.5, seed=3)
+        k, v = kv[:, :, :Cc], kv[:, :, Cc:]
+    # adversarial rows: one dominant logit, and an all-equal-logits query
+    q[0, 0] = 0
+    q[0, 1] = k[0, min(5, Nkv - 1)] * 4
+    vt = ops.transpose_v(v, heads)
+    out = ops.attention(q, k, vt, heads, 0.125)
+    close(out, attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Nq,Nkv", [(1024, 1024), (512, 77)])
+def test_attention_probability_borrowing(dev, dtype, Nq, Nkv):
+    """qk_src = [0,1,2,2]: cond1 uses cond0's probabilities with its own V (p2p_attention.py:124-138)."""
+    B, heads = 4, 4
+    Cc = heads * 64
+    q = rnd(B, Nq, Cc, dtype=dtype, dev=dev)
+    k = rnd(B, Nkv, Cc, dtype=dtype, dev=dev, seed=1)
+    v = rnd(B, Nkv, Cc, dtype=dtype, dev=dev, seed=2)
+    src = [0, 1, 2, 2]
+    vt = ops.transpose_v(v, heads)
+    out = ops.attention(q, k, vt, heads, 0.125, qk_src=torch.tensor(src, dtype=torch.int32, device=dev))
+    close(out, attn_ref(q, k, v, heads, 0.125, qk_src=src), dtype, scale=2.0)
+    # accumulate: O = text + 0.8 * ip  (ip_adapter/attention_processor.py:409)
+    k2 = rnd(B, 16, Cc, dtype=dtype, dev=dev, seed=4)
+    v2 = rnd(B, 16, Cc, dtype=dtype, dev=dev, seed=5)
+    base = out.clone()
+    ops.attention(q, k2, ops.transpose_v(v2, heads), heads, 0.125, out=out, accumulate=True, out_scale=0.8)
+    close(out, base.float().cpu() + 0.8 * attn_ref(q, k2, v2, heads, 0.125), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_protocol_mode(dev, dtype):
+    B, heads, Nq, Nkv = 2, 3, 130, 77
+    Cc = heads * 64
+    q = rnd(B, Nq, Cc, dtype=dtype, dev=dev)
+    k = rnd(B, Nkv, Cc, dtype=dtype, dev=dev, seed=1)
+    v = rnd(B, Nkv, Cc, dtype=dtype, dev=dev, seed=2)
+    p = ops.attn_probs(q, k, heads, 0.125)
+    def split(t):
+        return t.float().cpu().reshape(B, -1, heads, 64).permute(0, 2, 1, 3)
+    pref = torch.softmax(split(q) @ split(k).transpose(-1, -2) * 0.125, dim=-1).reshape(B * heads, Nq, Nkv)
+    close(p, pref, dtype)
+    o = ops.attn_apply_probs(p, v, heads)
+    oref = (p.float().cpu().reshape(B, heads, Nq, Nkv) @ split(v)).permute(0, 2, 1, 3).reshape(B, Nq, Cc)
+    close(o, oref, dtype)
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C1,C2,HW", [(320, 0, 1024), (640, 0, 300), (1280, 0, 64), (640, 320, 256), (1280, 640, 100), (1280, 1280, 64), (64, 0, 50)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(dev, dtype, C1, C2, HW, silu):
+    B = 2
+    x1 = rnd(B, HW, C1, dtype=dtype, dev=dev) * 2 + 0.5
+    x2 = (rnd(B, HW, C2, dtype=dtype, dev=dev, seed=8) - 1.0) if C2 else None
+    Cc = C1 + C2
+    g = rnd(Cc, dtype=dtype, dev=dev, seed=1)
+    b = rnd(Cc, dtype=dtype, dev=dev, seed=2)
+    y = ops.groupnorm(x1, g, b, 32, 1e-5, silu=silu, x2=x2)
+    xin = x1 if x2 is None else torch.cat([x1, x2], -1)
+    ref = F.group_norm(xin.float().cpu().transpose(1, 2), 32, g.float().cpu(), b.float().cpu(), 1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    close(y, ref, dtype, scale=2.0)
+    y2 = ops.groupnorm(x1, g, b, 32, 1e-5, silu=silu, x2=x2)
+    assert torch.equal(y, y2), "GroupNorm must be bitwise deterministic"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(300, 640), (77, 1280), (5, 64), (64, 2048)])
+def test_layernorm(dev, dtype, M, C):
+    x = rnd(M, C, dtype=dtype, dev=dev) * 3 + 1
+    g = rnd(C, dtype=dtype, dev=dev, seed=1)
+    b = rnd(C, dtype=dtype, dev=dev, seed=2)
+    y = ops.layernorm(x, g, b, 1e-5)
+    close(y, F.layer_norm(x.float().cpu(), (C,), g.float().cpu(), b.float().cpu(), 1e-5), dtype, scale=2.0)
+
+
+# ------------------------------------------------------------------ boundary convs & small ops
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_in_out(dev, dtype):
+    B, H, W, C0 = 2, 24, 20, 320
+    x = torch.randn(B, 4, H, W, generator=torch.Generator().manual_seed(0))
+    w = rnd(C0, 4, 3, 3, dtype=dtype, dev=dev, scale=1 / 6)
+    b = rnd(C0, dtype=dtype, dev=dev)
+    wp = w.permute(0, 2, 3, 1).contiguous()
+    y = ops.conv_in(x.to(dev), wp, b, dtype)
+    ref = F.conv2d(x, w.float().cpu(), b.float().cpu(), padding=1).permute(0, 2, 3, 1)
+    close(y, ref, dtype)
+    y16 = ops.conv_in(x.to(dtype).to(dev), wp, b, dtype)
+    close(y16, F.conv2d(x.to(dtype).float(), w.float().cpu(), b.float().cpu(), padding=1).permute(0, 2, 3, 1), dtype)
+    f = rnd(B, H, W, C0, dtype=dtype, dev=dev)
+    wo = rnd(4, C0, 3, 3, dtype=dtype, dev=dev, scale=(9 * C0) ** -0.5)
+    bo = rnd(4, dtype=dtype, dev=dev)
+    z = ops.conv_out(f, wo.permute(0, 2, 3, 1).contiguous(), bo)
+    zref = F.conv2d(f.float().cpu().permute(0, 3, 1, 2), wo.float().cpu(), bo.float().cpu(), padding=1)
+    torch.testing.assert_close(z.cpu(), zref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timestep_embedding_and_silu(dev, dtype):
+    t = torch.tensor([999.0, 981.0, 1.0, 0.0, 1024.0], device=dev)
+    e = ops.timestep_embedding(t, 320, dtype)
+    half = 160
+    freq = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t.cpu()[:, None] * freq[None]
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+    torch.testing.assert_close(e.float().cpu(), ref, rtol=0, atol=2e-3 if dtype == torch.float16 else 1e-2)
+    x = rnd(1000, dtype=dtype, dev=dev) * 4
+    close(ops.silu(x), F.silu(x.float().cpu()), dtype)
+    src = rnd(7, 40, dtype=dtype, dev=dev)
+    dst = torch.zeros(7, 100, dtype=dtype, device=dev)
+    ops.copy2d(src, dst[:, 16:56])
+    assert torch.equal(dst[:, 16:56], src) and dst[:, :16].abs().sum() == 0
