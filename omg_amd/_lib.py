@@ -107,6 +107,11 @@ def lib() -> C.CDLL:
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "omg_amd has no CPU fallback."
         )
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): it must be in the process
+    # BEFORE this library is, so that both resolve to ONE HIP runtime (streams, allocations and
+    # graph capture are shared).  Loading in the other order yields hipErrorNoDevice at first launch.
+    import torch  # noqa: F401
+
     l = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(l, name)  # AttributeError if the .so is stale

@@ -1,0 +1,242 @@
+"""Attention module + attention processors for the MI355X UNet.
+
+Boundary B1: the diffusers attention-processor protocol
+``proc(attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+**cross_attention_kwargs) -> Tensor`` as used by ``RegionControlNet_AttnProcessor``
+(/root/reference src/pipelines/lora_pipeline.py:61-133), installed with ``set_processor`` on
+modules whose class is named ``Attention`` (:139-140).
+
+Three processors are provided:
+
+* :class:`FusedAttnProcessor` — plain softmax(QK^T)V (what xformers / SDPA compute for the
+  concept UNet, src/ip_adapter/attention_processor.py:207-293).
+* :class:`RegionControlNet_AttnProcessor` — same name and constructor as the reference's class.
+  With an OMG ``AttentionReplace`` controller whose mapper is the identity and alpha is 1 (always,
+  in OMG's flows) the controller's in-place edit ``probs[cond_i] := probs[cond_0]`` is executed as
+  *probability borrowing* inside the flash-attention kernel (never materialising the
+  ``(B*heads, N, N)`` tensor).  For any other controller it falls back to the reference's literal
+  sequence (scores -> softmax -> controller(probs) -> bmm) on HIP kernels ("protocol mode").
+* :class:`IPAttnProcessor2_0` — text + scale * image-prompt attention of the InstantID concept
+  UNet (src/ip_adapter/attention_processor.py:296-424).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .modules import Dropout, Linear
+
+
+class Attention(nn.Module):
+    """The slice of ``diffusers.models.attention_processor.Attention`` that OMG touches."""
+
+    def __init__(self, query_dim: int, cross_attention_dim: Optional[int], heads: int, dim_head: int = 64,
+                 dtype=torch.float16, device=None):
+        super().__init__()
+        if dim_head != 64:
+            raise L.OmgHipError("the gfx950 attention kernel is specialised for head_dim 64 (all SDXL layers)")
+        inner = heads * dim_head
+        self.heads, self.scale, self.inner_dim = heads, dim_head ** -0.5, inner
+        self.is_cross = cross_attention_dim is not None
+        kv_dim = cross_attention_dim if self.is_cross else query_dim
+        self.to_q = Linear(query_dim, inner, bias=False, dtype=dtype, device=device)
+        self.to_k = Linear(kv_dim, inner, bias=False, dtype=dtype, device=device)
+        self.to_v = Linear(kv_dim, inner, bias=False, dtype=dtype, device=device)
+        self.to_out = nn.ModuleList([Linear(inner, query_dim, bias=True, dtype=dtype, device=device), Dropout()])
+        # attributes the reference processor reads (lora_pipeline.py:81-131)
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.processor = FusedAttnProcessor()
+        self._qkv = None          # fused [3*inner, C] weight for self-attention
+        self._kv = None           # fused [2*inner, Cx] weight for cross-attention
+        self._kv_cache = None     # (key, K/V^T projections) of a constant encoder_hidden_states
+
+    # ---- diffusers API
+    def set_processor(self, processor) -> None:
+        self.processor = processor
+
+    def get_processor(self):
+        return self.processor
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **cross_attention_kwargs):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **cross_attention_kwargs)
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        if attention_mask is not None:
+            raise L.OmgHipError("attention masks are not used on OMG's path (always None) and are not supported")
+        return None
+
+    def head_to_batch_dim(self, t: torch.Tensor) -> torch.Tensor:
+        B, N, _ = t.shape
+        return t.reshape(B, N, self.heads, 64).permute(0, 2, 1, 3).reshape(B * self.heads, N, 64)
+
+    def batch_to_head_dim(self, t: torch.Tensor) -> torch.Tensor:
+        BH, N, d = t.shape
+        return t.reshape(BH // self.heads, self.heads, N, d).permute(0, 2, 1, 3).reshape(BH // self.heads, N, self.heads * d)
+
+    def get_attention_scores(self, query: torch.Tensor, key: torch.Tensor, attention_mask=None) -> torch.Tensor:
+        """softmax(scale * Q K^T) as an explicit (B*heads, Nq, Nkv) tensor (protocol mode only)."""
+        if attention_mask is not None:
+            raise L.OmgHipError("attention masks are not supported")
+        q, k = query.contiguous(), key.contiguous()
+        return ops.attn_probs(q, k, 1, self.scale)      # batch' = B*heads, one head of 64
+
+    # ---- fused projections
+    def invalidate_packed(self):
+        self._qkv = self._kv = self._kv_cache = None
+
+    def qkv_weight(self) -> torch.Tensor:
+        if self._qkv is None:
+            self._qkv = torch.cat([self.to_q.weight.data, self.to_k.weight.data, self.to_v.weight.data], dim=0).contiguous()
+        return self._qkv
+
+    def kv_weight(self) -> torch.Tensor:
+        if self._kv is None:
+            self._kv = torch.cat([self.to_k.weight.data, self.to_v.weight.data], dim=0).contiguous()
+        return self._kv
+
+    def _has_lora(self) -> bool:
+        return self.to_q.lora_state is not None and self.to_q.lora_down is not None
+
+    def project_self(self, x: torch.Tensor):
+        """x (B,N,C) -> q, k views of one fused buffer, and V^T."""
+        B, N, C = x.shape
+        inner = self.inner_dim
+        if self._has_lora():
+            q = self.to_q(x); k = self.to_k(x); v = self.to_v(x)
+        else:
+            qkv = ops.gemm(x.reshape(B * N, C), self.qkv_weight()).view(B, N, 3 * inner)
+            q, k, v = qkv[:, :, :inner], qkv[:, :, inner:2 * inner], qkv[:, :, 2 * inner:]
+        return q, k, ops.transpose_v(v, self.heads)
+
+    def project_cross(self, ctx: torch.Tensor):
+        """ctx (B,Nk,Cx) -> k view and V^T; cached while the same ctx tensor (and LoRA state) is passed."""
+        st = self.to_k.lora_state
+        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), None if st is None else st.group_adapter.data_ptr())
+        if self._kv_cache is not None and self._kv_cache[0] == key:
+            return self._kv_cache[1], self._kv_cache[2]
+        B, Nk, Cx = ctx.shape
+        inner = self.inner_dim
+        if self._has_lora():
+            k = self.to_k(ctx); v = self.to_v(ctx)
+        else:
+            kv = ops.gemm(ctx.reshape(B * Nk, Cx), self.kv_weight()).view(B, Nk, 2 * inner)
+            k, v = kv[:, :, :inner], kv[:, :, inner:]
+        vt = ops.transpose_v(v, self.heads)
+        self._kv_cache = (key, k, vt, ctx)   # keep ctx alive so the pointer cannot be recycled
+        return k, vt
+
+
+def _to_tokens(attn, hidden_states):
+    if hidden_states.dim() == 4:
+        raise L.OmgHipError("4-D (NCHW) hidden_states are not produced by the SDXL transformer blocks; pass (B, N, C)")
+    return hidden_states
+
+
+class FusedAttnProcessor:
+    """softmax(QK^T/sqrt(d))V on the flash kernel.  ``residual`` (optional kwarg used by this
+    package's own BasicTransformerBlock) is added in the out-projection's epilogue."""
+
+    supports_fused_residual = True
+
+    def _qk_src(self, attn, is_cross: bool, n_tokens: int, batch: int, device):
+        return None
+
+    def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 scale: float = 1.0, residual: Optional[torch.Tensor] = None, **cross_attention_kwargs):
+        if attention_mask is not None:
+            raise L.OmgHipError("attention_mask is not supported")
+        x = _to_tokens(attn, hidden_states)
+        B, N, _ = x.shape
+        is_cross = encoder_hidden_states is not None
+        if is_cross:
+            q = attn.to_q(x)
+            k, vt = attn.project_cross(encoder_hidden_states)
+        else:
+            q, k, vt = attn.project_self(x)
+        bypass = cross_attention_kwargs.pop("omg_bypass_controller", False)
+        src = None if bypass else self._qk_src(attn, is_cross, N, B, x.device)
+        o = ops.attention(q, k, vt, attn.heads, attn.scale, qk_src=src)
+        out = attn.to_out[0](o, residual=residual)
+        return out
+
+
+class RegionControlNet_AttnProcessor(FusedAttnProcessor):
+    """Drop-in for the reference class of the same name (lora_pipeline.py:61-133)."""
+
+    def __init__(self, attention_op=None, controller=None, place_in_unet=None):
+        self.attention_op = attention_op
+        self.controller = controller
+        self.place_in_unet = place_in_unet
+
+    def _fusable(self) -> bool:
+        return self.controller is None or getattr(self.controller, "is_pure_replacement", False)
+
+    def _qk_src(self, attn, is_cross, n_tokens, batch, device):
+        if self.controller is None:
+            return None
+        return self.controller.fused_qk_src(is_cross, n_tokens, batch, self.place_in_unet, device=device)
+
+    def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 scale: float = 1.0, residual: Optional[torch.Tensor] = None, **cross_attention_kwargs):
+        if self._fusable() or cross_attention_kwargs.get("omg_bypass_controller", False):
+            return super().__call__(attn, hidden_states, encoder_hidden_states, attention_mask, temb, scale,
+                                    residual=residual, **cross_attention_kwargs)
+        # ---- protocol mode: the reference's literal sequence (lora_pipeline.py:98-124)
+        x = _to_tokens(attn, hidden_states)
+        is_cross = encoder_hidden_states is not None
+        src = encoder_hidden_states if is_cross else x
+        query = attn.head_to_batch_dim(attn.to_q(x))
+        key = attn.head_to_batch_dim(attn.to_k(src))
+        value = attn.to_v(src)
+        probs = attn.get_attention_scores(query, key, None)
+        probs = self.controller(probs, is_cross, self.place_in_unet)
+        o = ops.attn_apply_probs(probs.contiguous(), value, attn.heads)
+        return attn.to_out[0](o, residual=residual)
+
+
+class IPAttnProcessor2_0(nn.Module):
+    """InstantID / IP-Adapter cross-attention (src/ip_adapter/attention_processor.py:296-424):
+    the last ``num_tokens`` context rows are image-prompt tokens with their own K/V projections;
+    output = text attention + scale * ip attention (second kernel call accumulates)."""
+
+    supports_fused_residual = True
+
+    def __init__(self, hidden_size: int, cross_attention_dim: Optional[int] = None, scale: float = 1.0, num_tokens: int = 4,
+                 dtype=torch.float16, device=None):
+        super().__init__()
+        self.hidden_size, self.cross_attention_dim, self.scale, self.num_tokens = hidden_size, cross_attention_dim, scale, num_tokens
+        self.to_k_ip = Linear(cross_attention_dim or hidden_size, hidden_size, bias=False, dtype=dtype, device=device)
+        self.to_v_ip = Linear(cross_attention_dim or hidden_size, hidden_size, bias=False, dtype=dtype, device=device)
+
+    def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                 residual: Optional[torch.Tensor] = None, **kw):
+        if attention_mask is not None:
+            raise L.OmgHipError("attention_mask is not supported")
+        x = _to_tokens(attn, hidden_states)
+        if encoder_hidden_states is None:
+            q, k, vt = attn.project_self(x)
+            o = ops.attention(q, k, vt, attn.heads, attn.scale)
+            return attn.to_out[0](o, residual=residual)
+        end = encoder_hidden_states.shape[1] - self.num_tokens
+        text, ip = encoder_hidden_states[:, :end], encoder_hidden_states[:, end:]
+        q = attn.to_q(x)
+        B, Nt, Cx = text.shape
+        k = attn.to_k(text.reshape(B * Nt, Cx)).view(B, Nt, -1)
+        v = attn.to_v(text.reshape(B * Nt, Cx)).view(B, Nt, -1)
+        o = ops.attention(q, k, ops.transpose_v(v, attn.heads), attn.heads, attn.scale)
+        Ni = ip.shape[1]
+        ipc = ip.reshape(B * Ni, Cx)
+        k_ip = self.to_k_ip(ipc).view(B, Ni, -1)
+        v_ip = self.to_v_ip(ipc).view(B, Ni, -1)
+        ops.attention(q, k_ip, ops.transpose_v(v_ip, attn.heads), attn.heads, attn.scale, out=o, accumulate=True,
+                      out_scale=self.scale)
+        return attn.to_out[0](o, residual=residual)

@@ -334,8 +334,8 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   AttnP p = make_params(a);
   dim3 grid((a->Nq + QB - 1) / QB, a->heads, a->B);
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == OMG_F16) hipLaunchKernelGGL(attn_fwd_kernel<f16>, grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel<bf16>, grid, dim3(256), 0, s, p);
+  if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel<f16>, grid, dim3(256), 0, s, p);
+  else OMG_LAUNCH(attn_fwd_kernel<bf16>, grid, dim3(256), 0, s, p);
   return omg_check_launch("attn_fwd");
 }
 
@@ -345,8 +345,8 @@ extern "C" int omg_transpose_v(int dtype, const void* V, int64_t ldv, int64_t v_
   OMG_REQUIRE(V && Vt && Nkv_pad % 64 == 0 && Nkv_pad >= Nkv && ldv % 8 == 0, "omg_transpose_v: args");
   dim3 grid(Nkv_pad / 64, heads, B);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OMG_F16) hipLaunchKernelGGL(transpose_v_kernel<f16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt);
-  else hipLaunchKernelGGL(transpose_v_kernel<bf16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt);
+  if (dtype == OMG_F16) OMG_LAUNCH(transpose_v_kernel<f16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt);
+  else OMG_LAUNCH(transpose_v_kernel<bf16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt);
   return omg_check_launch("transpose_v");
 }
 
@@ -357,8 +357,8 @@ extern "C" int omg_attn_probs(const omg_attn_args* a, void* P, void* stream) {
   AttnP p = make_params(a);
   dim3 grid((a->Nq + 3) / 4, a->heads, a->B);
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == OMG_F16) hipLaunchKernelGGL(attn_probs_kernel<f16>, grid, dim3(256), 0, s, p, (char*)P);
-  else hipLaunchKernelGGL(attn_probs_kernel<bf16>, grid, dim3(256), 0, s, p, (char*)P);
+  if (a->dtype == OMG_F16) OMG_LAUNCH(attn_probs_kernel<f16>, grid, dim3(256), 0, s, p, (char*)P);
+  else OMG_LAUNCH(attn_probs_kernel<bf16>, grid, dim3(256), 0, s, p, (char*)P);
   return omg_check_launch("attn_probs");
 }
 
@@ -368,7 +368,7 @@ extern "C" int omg_attn_apply_probs(int dtype, const void* P, const void* V, int
   OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_attn_apply_probs: dtype");
   dim3 grid((Nq + 3) / 4, heads, B);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OMG_F16) hipLaunchKernelGGL(attn_apply_probs_kernel<f16>, grid, dim3(256), 0, s, (const char*)P, (const char*)V, (long)ldv, (long)v_bstride, heads, Nq, Nkv, (char*)O, (long)ldo, (long)o_bstride);
-  else hipLaunchKernelGGL(attn_apply_probs_kernel<bf16>, grid, dim3(256), 0, s, (const char*)P, (const char*)V, (long)ldv, (long)v_bstride, heads, Nq, Nkv, (char*)O, (long)ldo, (long)o_bstride);
+  if (dtype == OMG_F16) OMG_LAUNCH(attn_apply_probs_kernel<f16>, grid, dim3(256), 0, s, (const char*)P, (const char*)V, (long)ldv, (long)v_bstride, heads, Nq, Nkv, (char*)O, (long)ldo, (long)o_bstride);
+  else OMG_LAUNCH(attn_apply_probs_kernel<bf16>, grid, dim3(256), 0, s, (const char*)P, (const char*)V, (long)ldv, (long)v_bstride, heads, Nq, Nkv, (char*)O, (long)ldo, (long)o_bstride);
   return omg_check_launch("attn_apply_probs");
 }

@@ -57,4 +57,6 @@ static inline int omg_check_launch(const char* what) {
   if (e != hipSuccess) { omg_set_error(hipGetErrorString(e)); (void)what; return OMG_ELAUNCH; }
   return OMG_OK;
 }
+// clear any stale sticky error left by an unrelated runtime call, then launch
+#define OMG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define OMG_REQUIRE(cond, msg) do { if (!(cond)) { omg_set_error(msg); return OMG_EINVAL; } } while (0)

@@ -310,9 +310,9 @@ int launch(const GemmP& p, hipStream_t s) {
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
   if (g_use_glds) {
-    hipLaunchKernelGGL((gemm_kernel<T, CONV, true>), dim3(grid), dim3(256), LDS_BYTES, s, p);
+    OMG_LAUNCH((gemm_kernel<T, CONV, true>), dim3(grid), dim3(256), LDS_BYTES, s, p);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, CONV, false>), dim3(grid), dim3(256), LDS_BYTES, s, p);
+    OMG_LAUNCH((gemm_kernel<T, CONV, false>), dim3(grid), dim3(256), LDS_BYTES, s, p);
   }
   return omg_check_launch("gemm");
 }

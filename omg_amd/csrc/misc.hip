@@ -211,11 +211,11 @@ extern "C" int omg_conv_in(int dtype, const void* X, int x_is_f32, int B, int Ci
   long blocks = (npix + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OMG_F16) {
-    if (x_is_f32) hipLaunchKernelGGL((conv_in_kernel<f16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
-    else hipLaunchKernelGGL((conv_in_kernel<f16, f16>), dim3(blocks), dim3(256), lds, s, (const f16*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
+    if (x_is_f32) OMG_LAUNCH((conv_in_kernel<f16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
+    else OMG_LAUNCH((conv_in_kernel<f16, f16>), dim3(blocks), dim3(256), lds, s, (const f16*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
   } else {
-    if (x_is_f32) hipLaunchKernelGGL((conv_in_kernel<bf16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
-    else hipLaunchKernelGGL((conv_in_kernel<bf16, bf16>), dim3(blocks), dim3(256), lds, s, (const bf16*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
+    if (x_is_f32) OMG_LAUNCH((conv_in_kernel<bf16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
+    else OMG_LAUNCH((conv_in_kernel<bf16, bf16>), dim3(blocks), dim3(256), lds, s, (const bf16*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
   }
   return omg_check_launch("conv_in");
 }
@@ -228,8 +228,8 @@ extern "C" int omg_conv_out(int dtype, const void* X, int B, int H, int W, int C
   if (npix == 0) return OMG_OK;
   long blocks = (npix + 3) / 4; if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OMG_F16) hipLaunchKernelGGL(conv_out_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Cout, Y);
-  else hipLaunchKernelGGL(conv_out_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
+  if (dtype == OMG_F16) OMG_LAUNCH(conv_out_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Cout, Y);
+  else OMG_LAUNCH(conv_out_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
   return omg_check_launch("conv_out");
 }
 
@@ -238,8 +238,8 @@ extern "C" int omg_timestep_embedding(int dtype, const float* t, int n, int dim,
   OMG_REQUIRE(t && out && dim % 2 == 0 && n >= 0, "omg_timestep_embedding: args");
   if (n == 0) return OMG_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OMG_F16) hipLaunchKernelGGL(timestep_embedding_kernel<f16>, dim3(n), dim3(128), 0, s, t, n, dim, (f16*)out, (long)ldo);
-  else hipLaunchKernelGGL(timestep_embedding_kernel<bf16>, dim3(n), dim3(128), 0, s, t, n, dim, (bf16*)out, (long)ldo);
+  if (dtype == OMG_F16) OMG_LAUNCH(timestep_embedding_kernel<f16>, dim3(n), dim3(128), 0, s, t, n, dim, (f16*)out, (long)ldo);
+  else OMG_LAUNCH(timestep_embedding_kernel<bf16>, dim3(n), dim3(128), 0, s, t, n, dim, (bf16*)out, (long)ldo);
   return omg_check_launch("timestep_embedding");
 }
 
@@ -249,8 +249,8 @@ extern "C" int omg_silu(int dtype, const void* x, void* y, int64_t n, void* stre
   if (n == 0) return OMG_OK;
   long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OMG_F16) hipLaunchKernelGGL(silu_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const f16*)x, (f16*)y, (long)n);
-  else hipLaunchKernelGGL(silu_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)n);
+  if (dtype == OMG_F16) OMG_LAUNCH(silu_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const f16*)x, (f16*)y, (long)n);
+  else OMG_LAUNCH(silu_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)n);
   return omg_check_launch("silu");
 }
 
@@ -262,7 +262,7 @@ extern "C" int omg_copy2d(int dtype, const void* src, int64_t lds_, void* dst, i
   long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
   hipStream_t s = (hipStream_t)stream;
   // f16 and bf16 are both 2-byte copies
-  hipLaunchKernelGGL(copy2d_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)src, (long)lds_, (uint16_t*)dst, (long)ldd, (long)rows, (long)cols);
+  OMG_LAUNCH(copy2d_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)src, (long)lds_, (uint16_t*)dst, (long)ldd, (long)rows, (long)cols);
   return omg_check_launch("copy2d");
 }
 
@@ -281,8 +281,8 @@ extern "C" int omg_fuse_cfg_step(const omg_step_args* a, void* stream) {
   const int n = a->C * a->H * a->W;
   int blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(step_kernel, dim3(blocks), dim3(256), 0, s, p);
-  if (a->advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, a->step_idx);
+  OMG_LAUNCH(step_kernel, dim3(blocks), dim3(256), 0, s, p);
+  if (a->advance) OMG_LAUNCH(step_advance_kernel, dim3(1), dim3(1), 0, s, a->step_idx);
   return omg_check_launch("fuse_cfg_step");
 }
 
@@ -290,6 +290,6 @@ extern "C" int omg_scale_model_input(int dtype, const float* latents, const floa
   OMG_REQUIRE(latents && coef_cin && out, "omg_scale_model_input: null");
   OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16 || dtype == 2, "omg_scale_model_input: dtype");
   int blocks = (2 * n_per_sample + 255) / 256; if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(scale_model_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, latents, coef_cin, n_per_sample, dtype, out);
+  OMG_LAUNCH(scale_model_input_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, latents, coef_cin, n_per_sample, dtype, out);
   return omg_check_launch("scale_model_input");
 }

@@ -223,11 +223,11 @@ extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, 
   dim3 grid(nchunk, B);
   const size_t lds = (size_t)2 * p.pr * C * sizeof(float);
   if (dtype == OMG_F16) {
-    hipLaunchKernelGGL(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
-    hipLaunchKernelGGL(gn_apply_kernel<f16>, grid, dim3(256), 0, s, p);
+    OMG_LAUNCH(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
+    OMG_LAUNCH(gn_apply_kernel<f16>, grid, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
-    hipLaunchKernelGGL(gn_apply_kernel<bf16>, grid, dim3(256), 0, s, p);
+    OMG_LAUNCH(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
+    OMG_LAUNCH(gn_apply_kernel<bf16>, grid, dim3(256), 0, s, p);
   }
   return omg_check_launch("groupnorm");
 }
@@ -241,7 +241,7 @@ extern "C" int omg_layernorm(int dtype, const void* X, int64_t ldx, int M, int C
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((M + 3) / 4);
   const int nv = (C / 8 + 63) / 64;
-#define LN_LAUNCH(TT, NVV) hipLaunchKernelGGL((ln_kernel<TT, NVV>), grid, dim3(256), 0, s, (const char*)X, (long)ldx, M, C, eps, (const char*)gamma, (const char*)beta, (char*)Y, (long)ldy)
+#define LN_LAUNCH(TT, NVV) OMG_LAUNCH((ln_kernel<TT, NVV>), grid, dim3(256), 0, s, (const char*)X, (long)ldx, M, C, eps, (const char*)gamma, (const char*)beta, (char*)Y, (long)ldy)
   if (dtype == OMG_F16) {
     switch (nv) { case 1: LN_LAUNCH(f16, 1); break; case 2: LN_LAUNCH(f16, 2); break; case 3: LN_LAUNCH(f16, 3); break; default: LN_LAUNCH(f16, 4); }
   } else {

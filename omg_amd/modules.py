@@ -1,0 +1,168 @@
+"""Parameter-holding building blocks of the MI355X UNet.
+
+They are ``torch.nn.Module`` only so that ``state_dict()`` / ``load_state_dict()`` speak the
+diffusers key layout ("state-dict keys must equal diffusers' so real
+checkpoints load"); every ``forward`` dispatches to a HIP kernel through :mod:`omg_amd.ops`.
+Activations are NHWC / token-major ``(B, H*W, C)`` everywhere inside the network.
+
+Derived weight images (conv weights repacked to ``[Cout][ky][kx][Cin]``, GEGLU rows interleaved,
+q|k|v concatenated) are built lazily from the canonical parameters and invalidated by
+``load_state_dict`` / ``invalidate_packed``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+
+
+class LoraState:
+    """Per-forward LoRA selection: which adapter slot each sample of the batch uses (-1 = none)."""
+
+    __slots__ = ("group_adapter", "groups")
+
+    def __init__(self, group_adapter: torch.Tensor, groups: int):
+        self.group_adapter = group_adapter   # int32 device tensor [groups]
+        self.groups = groups
+
+
+class _Packed(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._packed = {}
+
+    def invalidate_packed(self):
+        self._packed = {}
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = {}
+        return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
+
+class Linear(_Packed):
+    """nn.Linear replacement; optional stacked LoRA adapters (``lora_down``/``lora_up`` buffers).
+
+    ``forward(x, scale=None)`` accepts and ignores diffusers' legacy positional ``scale`` so that the
+    reference processor's ``attn.to_q(hidden_states, *args)`` (lora_pipeline.py:98) works unchanged.
+    """
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, dtype=torch.float16, device=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, dtype=dtype, device=device), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_features, dtype=dtype, device=device), requires_grad=False) if bias else None
+        # LoRA bank (set by omg_amd.lora.LoraBank): [slots, r, in], [slots, out, r] (up already scaled)
+        self.lora_down: Optional[torch.Tensor] = None
+        self.lora_up: Optional[torch.Tensor] = None
+        self.lora_state: Optional[LoraState] = None   # set per forward by the UNet
+
+    def _lora(self, x2: torch.Tensor) -> Optional[ops.LoraSpec]:
+        st = self.lora_state
+        if st is None or self.lora_down is None:
+            return None
+        t = ops.gemm(x2, self.lora_down, groups=st.groups, w_group_adapter=st.group_adapter)
+        return ops.LoraSpec(t, self.lora_up, st.group_adapter)
+
+    def forward(self, x: torch.Tensor, scale=None, *, residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE,
+                group_bias: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        lora = self._lora(x2)
+        if lora is not None:
+            groups = self.lora_state.groups
+            if x2.shape[0] % groups != 0:
+                raise L.OmgHipError("LoRA groups do not divide the row count")
+        r2 = residual.reshape(-1, self.out_features) if residual is not None else None
+        y = ops.gemm(x2, self.weight, bias=self.bias, residual=r2, act=act, group_bias=group_bias, groups=groups, lora=lora)
+        return y.view(*shp[:-1], y.shape[-1])
+
+
+class GEGLU(_Packed):
+    """diffusers attention.GEGLU: ``proj`` Linear(C -> 8C) then value * gelu(gate), fused in the GEMM epilogue."""
+
+    def __init__(self, dim_in: int, dim_out: int, dtype=torch.float16, device=None):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2, dtype=dtype, device=device)
+
+    def _packed_w(self):
+        if "w" not in self._packed:
+            perm = ops.geglu_row_perm(self.proj.out_features).to(self.proj.weight.device)
+            self._packed["w"] = self.proj.weight.data[perm].contiguous()
+            self._packed["b"] = self.proj.bias.data[perm].contiguous()
+            if self.proj.lora_up is not None:
+                self._packed["up"] = self.proj.lora_up[:, perm].contiguous()
+        return self._packed
+
+    def invalidate_packed(self):
+        super().invalidate_packed()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        pk = self._packed_w()
+        lora = None
+        groups = 1
+        st = self.proj.lora_state
+        if st is not None and self.proj.lora_down is not None:
+            t = ops.gemm(x2, self.proj.lora_down, groups=st.groups, w_group_adapter=st.group_adapter)
+            lora = ops.LoraSpec(t, pk["up"], st.group_adapter)
+            groups = st.groups
+        y = ops.gemm(x2, pk["w"], bias=pk["b"], act=L.ACT_GEGLU, groups=groups, lora=lora)
+        return y.view(*shp[:-1], y.shape[-1])
+
+
+class Conv2d(_Packed):
+    """3x3 (pad 1) or 1x1 conv on NHWC activations; canonical weight is diffusers' OIHW."""
+
+    def __init__(self, cin: int, cout: int, ksize: int, stride: int = 1, dtype=torch.float16, device=None):
+        super().__init__()
+        self.cin, self.cout, self.ksize, self.stride = cin, cout, ksize, stride
+        self.weight = nn.Parameter(torch.empty(cout, cin, ksize, ksize, dtype=dtype, device=device), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(cout, dtype=dtype, device=device), requires_grad=False)
+
+    def packed_weight(self) -> torch.Tensor:
+        if "w" not in self._packed:
+            self._packed["w"] = ops.pack_conv_weight(self.weight.data)
+        return self._packed["w"]
+
+    def forward(self, x: torch.Tensor, *, x2: Optional[torch.Tensor] = None, upsample: bool = False,
+                group_bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return ops.conv2d(x, self.packed_weight(), self.ksize, stride=self.stride, upsample=upsample, x2=x2, bias=self.bias,
+                          group_bias=group_bias, residual=residual)
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, groups: int, channels: int, eps: float, dtype=torch.float16, device=None):
+        super().__init__()
+        self.groups, self.eps = groups, eps
+        self.weight = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
+
+    def forward(self, x: torch.Tensor, *, x2: Optional[torch.Tensor] = None, silu: bool = False) -> torch.Tensor:
+        return ops.groupnorm(x, self.weight, self.bias, self.groups, self.eps, silu=silu, x2=x2)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, channels: int, eps: float = 1e-5, dtype=torch.float16, device=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.layernorm(x, self.weight, self.bias, self.eps)
+
+
+class Dropout(nn.Module):
+    """p = 0 at inference: identity (kept so that ``attn.to_out[1]`` exists, lora_pipeline.py:123)."""
+
+    def forward(self, x):
+        return x

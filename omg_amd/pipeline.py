@@ -1,0 +1,272 @@
+"""OMG's two-stage denoising loop on the MI355X — boundary B3 of SURVEY.md §8b.
+
+Mirrors ``LoraMultiConceptPipeline.__call__`` (/root/reference src/pipelines/lora_pipeline.py:212-669):
+same keyword names and meaning for everything on the hot path (``num_inference_steps``,
+``guidance_scale``, ``generator``/``latents``, ``cross_attention_kwargs={"scale": 0.8}``, ``controller``,
+``concept_models``, ``stage`` in {1, 2}, ``region_masks``, ``lora_list``, ``styleL``), and the same batch
+layout: latents duplicated x2 (:409), model input ``[unc0, unc1, cond0, cond1]`` (:467-474, :491), concept
+pass on ``latent_model_input[3:4]`` duplicated (:583-585), fusion for ``i > 15 and stage == 2`` (:568).
+
+What is NOT here (rows marked "next" in SURVEY §8f): text encoders and the VAE.  The call therefore takes
+``prompt_embeds`` / pooled embeddings (the reference computes them at :315-347 and passes them on) and
+returns latents (``output_type="latent"``); ``prompt=``/``output_type="pil"`` work only if the caller
+supplies ``encode_prompt`` / ``vae_decode`` callables.
+
+MI355X-first differences from the reference's loop, all value-preserving:
+  * the K per-concept UNet passes of a step run as ONE batched forward with a per-sample LoRA slot;
+  * time/text-conditioning embeddings of all steps are computed once before the loop;
+  * fusion + CFG + scheduler step + next model input are one kernel, masks stay on the device
+    (the reference copies each mask to the host every step and boolean-indexes, :572-602, :675-679);
+  * each step regime (plain / fused, self-replace on / off) can be captured as a hipGraph.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .attention import Attention, RegionControlNet_AttnProcessor
+from .lora import LoraBank
+from .modules import LoraState
+from .schedulers import DDIMScheduler
+
+FUSION_START = 15   # `if i > 15 and stage == 2` (lora_pipeline.py:568) — absolute, not relative
+
+
+def revise_regionally_controlnet_forward(unet, controller) -> None:
+    """Install the region/controller attention processor on every ``Attention`` of the UNet and set
+    ``controller.num_att_layers`` — same name, traversal order and place labels (including the
+    mid/up label swap, harmless because the label is unused) as lora_pipeline.py:136-152."""
+
+    def change_forward(module, count, place_in_unet):
+        for name, layer in module.named_children():
+            if layer.__class__.__name__ == "Attention":
+                layer.set_processor(RegionControlNet_AttnProcessor(controller=controller, place_in_unet=place_in_unet))
+                if "attn2" in name:
+                    count += 1
+            else:
+                count = change_forward(layer, count, place_in_unet)
+        return count
+
+    n = change_forward(unet.down_blocks, 0, "down")
+    n = change_forward(unet.mid_block, n, "up")
+    n = change_forward(unet.up_blocks, n, "mid")
+    print(f"Number of attention layer registered {n}")
+    controller.num_att_layers = n * 2
+
+
+class ConceptModels:
+    """What the reference's loop needs from ``concept_models`` (a second SDXL pipeline with the concept
+    LoRAs loaded; inference_lora.py:159-170): ``unet(...)``, ``set_adapters(...)``, ``_execution_device``.
+    Here the concept UNet shares the base weights of the main UNet; adapters live in a :class:`LoraBank`."""
+
+    def __init__(self, unet, bank: Optional[LoraBank] = None):
+        self._unet = unet
+        self.bank = bank
+        self._active: Tuple[Tuple[str, float], ...] = ()
+        self._state_cache: Dict[Tuple, LoraState] = {}
+
+    @property
+    def _execution_device(self):
+        return self._unet.device
+
+    def set_adapters(self, adapter_names, adapter_weights=None) -> None:
+        if isinstance(adapter_names, str):
+            adapter_names = [adapter_names]
+        if adapter_weights is None:
+            adapter_weights = [1.0] * len(adapter_names)
+        self._active = tuple((n, float(w)) for n, w in zip(adapter_names, adapter_weights))
+
+    def lora_state(self, slots: Sequence[int]) -> Optional[LoraState]:
+        if self.bank is None:
+            return None
+        key = tuple(slots)
+        st = self._state_cache.get(key)
+        if st is None:
+            st = LoraState(torch.tensor(list(slots), dtype=torch.int32, device=self._unet.device), len(slots))
+            self._state_cache[key] = st
+        return st
+
+    def unet_batched(self, sample, timestep, encoder_hidden_states, slots: Sequence[int], **kw):
+        """Concept forward where sample b uses LoRA slot ``slots[b]``; bypasses the p2p controller."""
+        cak = dict(kw.pop("cross_attention_kwargs", None) or {})
+        cak["omg_bypass_controller"] = True
+        self._unet.set_lora_state(self.lora_state(slots))
+        try:
+            return self._unet(sample, timestep, encoder_hidden_states=encoder_hidden_states, cross_attention_kwargs=cak, **kw)
+        finally:
+            self._unet.set_lora_state(None)
+
+    def unet(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+             return_dict=False, **kw):
+        """Reference call shape (lora_pipeline.py:592-599): whole batch uses the adapters chosen by ``set_adapters``."""
+        slot = self.bank.slot_of(self._active) if self.bank is not None and self._active else -1
+        return self.unet_batched(sample, timestep, encoder_hidden_states, [slot] * sample.shape[0],
+                                 cross_attention_kwargs=cross_attention_kwargs, added_cond_kwargs=added_cond_kwargs,
+                                 return_dict=return_dict, **kw)
+
+
+class StableDiffusionXLPipelineOutput(SimpleNamespace):
+    pass
+
+
+class LoraMultiConceptPipeline:
+    def __init__(self, unet, scheduler=None, encode_prompt: Optional[Callable] = None, vae_decode: Optional[Callable] = None):
+        self.unet = unet
+        self.scheduler = scheduler or DDIMScheduler()
+        self.encode_prompt = encode_prompt
+        self.vae_decode = vae_decode
+        self.vae_scale_factor = 8
+        self._graphs: Dict[Tuple, object] = {}
+
+    @property
+    def _execution_device(self):
+        return self.unet.device
+
+    # ------------------------------------------------------------------ helpers
+    def prepare_latents(self, batch, channels, height, width, dtype, device, generator, latents=None):
+        """randn / vae_scale_factor, times init_noise_sigma (diffusers prepare_latents; lora_pipeline.py:397-406).
+        ``latents=`` injects fixed noise (needed for CPU<->GPU seed parity)."""
+        shape = (batch, channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            gen_dev = generator.device if generator is not None else device
+            latents = torch.randn(shape, generator=generator, device=gen_dev, dtype=torch.float32).to(device)
+        else:
+            latents = latents.to(device=device, dtype=torch.float32)
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"latents shape {tuple(latents.shape)} != {shape}")
+        return latents * float(self.scheduler.init_noise_sigma)
+
+    @staticmethod
+    def _add_time_ids(original_size, crops, target_size, n, device):
+        ids = list(original_size) + list(crops) + list(target_size)
+        return torch.tensor([ids] * n, dtype=torch.float32, device=device)
+
+    # ------------------------------------------------------------------ the call
+    @torch.no_grad()
+    def __call__(self, prompt=None, prompt_2=None, image=None, height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 5.0, negative_prompt=None, negative_prompt_2=None,
+                 num_images_per_prompt: int = 1, eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None,
+                 output_type: str = "latent", return_dict: bool = True, cross_attention_kwargs=None,
+                 original_size=None, crops_coords_top_left=(0, 0), target_size=None,
+                 controller=None, concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None,
+                 region_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, lora_list: Optional[Sequence[str]] = None,
+                 styleL: Optional[bool] = None, region_prompt_embeds: Optional[Sequence[Tuple[torch.Tensor, ...]]] = None,
+                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, **kwargs):
+        if image is not None:
+            raise L.OmgHipError("ControlNet conditioning (image=) is a 'next' row of SURVEY §8f (N2) and is not implemented")
+        if eta != 0.0:
+            raise L.OmgHipError("eta != 0 (stochastic DDIM) is not used by OMG and is not supported")
+        dev, dt = self.unet.device, self.unet.dtype
+        batch_size = 2                                                           # lora_pipeline.py:291
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        lora_list = list(lora_list or [])
+        K = len(lora_list)
+        # ---- 3. prompt embeddings (global on the main pipe; per-region on the concept pipe)
+        if prompt_embeds is None:
+            if self.encode_prompt is None:
+                raise L.OmgHipError("text encoders are outside this package's scope: pass prompt_embeds=/pooled_prompt_embeds= "
+                                    "(and region_prompt_embeds=) or construct the pipeline with encode_prompt=")
+            global_prompt, regions = prompt[0], prompt[1]
+            prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = self.encode_prompt(
+                global_prompt, negative_prompt, None)
+            region_prompt_embeds = []
+            for lora_param, (rp, rn) in zip(lora_list, [(r[0], r[1]) for r in regions]):
+                pe, ne, pp, npp = self.encode_prompt(rp, rn, lora_param)
+                region_prompt_embeds.append((ne, pe, npp, pp))
+        if prompt_embeds.shape[0] != batch_size:
+            raise ValueError("prompt_embeds must hold the 2 global prompts [p, p] (lora_pipeline.py:291)")
+        if region_prompt_embeds is None:
+            region_prompt_embeds = []
+        if len(region_prompt_embeds) != K:
+            raise ValueError("one (neg_embeds, pos_embeds, neg_pooled, pos_pooled) tuple per entry of lora_list is required")
+        # ---- 5./6. timesteps and latents (duplicated x2, :409)
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        lat = self.prepare_latents(batch_size // 2 * num_images_per_prompt, self.unet.config.in_channels, height, width,
+                                   torch.float32, dev, generator, latents)
+        lat = torch.cat([lat, lat.clone()]).contiguous()
+        Hl, Wl = lat.shape[2:]
+        # ---- 7.2 added time ids, CFG concat order [neg, pos] (:467-474)
+        original_size = original_size or (height, width)
+        target_size = target_size or (height, width)
+        ehs = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(device=dev, dtype=dt).contiguous()
+        text = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0).to(device=dev, dtype=dt)
+        tids = self._add_time_ids(original_size, crops_coords_top_left, target_size, 2 * batch_size, dev)
+        S = num_inference_steps
+        ts = self.scheduler.timesteps.to(torch.float32)
+        emb_main = self._all_step_embeddings(ts, text, tids)                       # (S, 4, D)
+        # ---- concepts that take part (mask is not None), batched with per-sample LoRA slots
+        masks: List[Optional[torch.Tensor]] = [None] * K
+        if stage == 2:
+            if region_masks is None or len(region_masks) != K:
+                raise ValueError("stage 2 needs one region mask (or None) per entry of lora_list")
+            masks = [m.to(device=dev, dtype=torch.float32).contiguous() if m is not None else None for m in region_masks]
+        active = [c for c in range(K) if masks[c] is not None]
+        fuse_possible = stage == 2 and len(active) > 0 and S > fusion_start + 1
+        slots: List[int] = []
+        if fuse_possible:
+            if concept_models is None:
+                raise ValueError("stage 2 needs concept_models")
+            scale = (cross_attention_kwargs or {}).get("scale", 1.0)
+            combos = [((lora_list[c], 0.7), ("style", 0.5)) if styleL else ((lora_list[c], 1.0),) for c in active]
+            if concept_models.bank is not None:
+                if [tuple(c) for c in combos] != list(concept_models.bank.slots) or concept_models.bank.scale != scale:
+                    concept_models.bank.build(combos, scale=scale)
+                slots = [s for s in range(len(active)) for _ in range(2)]
+            else:
+                slots = [-1] * (2 * len(active))
+            c_ehs = torch.cat([torch.cat([region_prompt_embeds[c][0], region_prompt_embeds[c][1]], dim=0) for c in active], dim=0)
+            c_ehs = c_ehs.to(device=dev, dtype=dt).contiguous()                   # (2Ka, 77, Cx) = [unc, cond] per concept
+            c_text = torch.cat([torch.cat([region_prompt_embeds[c][2], region_prompt_embeds[c][3]], dim=0) for c in active], dim=0)
+            c_tids = self._add_time_ids(original_size, crops_coords_top_left, target_size, 2 * len(active), dev)
+            emb_conc = self._all_step_embeddings(ts, c_text.to(device=dev, dtype=dt), c_tids)   # (S, 2Ka, D)
+        # ---- persistent step buffers
+        coef = self.scheduler.coef_table(dev)
+        step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        model_input = torch.empty((4, lat.shape[1], Hl, Wl), dtype=dt, device=dev)
+        ops.scale_model_input(lat, self.scheduler.cin0(dev), model_input)
+        noise = torch.empty((4, lat.shape[1], Hl, Wl), dtype=torch.float32, device=dev)
+        Ka = len(active)
+        region_noise = torch.empty((max(Ka, 1) * 2, lat.shape[1], Hl, Wl), dtype=torch.float32, device=dev)
+        region_in = torch.empty((max(Ka, 1) * 2, lat.shape[1], Hl, Wl), dtype=dt, device=dev)
+        region_list: List[Optional[torch.Tensor]] = [None] * K
+        for j, c in enumerate(active):
+            region_list[c] = region_noise[2 * j: 2 * j + 2]
+        main_kw = dict(cross_attention_kwargs or {})
+        main_kw.pop("scale", None)
+
+        def one_step(i: int, fused: bool):
+            self.unet(model_input, None, encoder_hidden_states=ehs, cross_attention_kwargs=main_kw, emb=emb_main[i], out=noise)
+            if fused:
+                region_in.copy_(model_input[3:4].expand(2 * Ka, -1, -1, -1))      # latent_model_input[3:4] duplicated (:583-585)
+                concept_models.unet_batched(region_in, None, c_ehs, slots, emb=emb_conc[i], out=region_noise)
+            ops.fuse_cfg_step(noise, lat, coef, step_idx, guidance_scale=guidance_scale, fuse=fused,
+                              region_preds=region_list if fused else [None] * K, masks=masks if fused else [None] * K,
+                              model_input_next=model_input, advance=True)
+
+        # ---- 8. denoising loop
+        for i in range(S):
+            one_step(i, fuse_possible and i > fusion_start)
+            if trajectory is not None:
+                trajectory.append(lat.clone())
+        if output_type == "latent":
+            images = lat
+        else:
+            if self.vae_decode is None:
+                raise L.OmgHipError("VAE decode is a 'next' row (SURVEY §8f N1): use output_type='latent' or pass vae_decode=")
+            images = self.vae_decode(lat)
+        if not return_dict:
+            return (images,)
+        return StableDiffusionXLPipelineOutput(images=images)
+
+    def _all_step_embeddings(self, ts: torch.Tensor, text: torch.Tensor, tids: torch.Tensor) -> torch.Tensor:
+        """emb[i] for every step in one batched pass: (S, B, 4*C0).  Depends only on (t_i, pooled text, time ids)."""
+        S, B = ts.numel(), text.shape[0]
+        t_all = ts.reshape(S, 1).expand(S, B).reshape(-1).contiguous()
+        emb = self.unet.time_embed(t_all, S * B, text.repeat(S, 1), tids.repeat(S, 1))
+        return emb.view(S, B, -1)

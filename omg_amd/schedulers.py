@@ -1,0 +1,114 @@
+"""DDIM and Euler-discrete schedules for the SDXL-base scheduler config, exported as per-step
+coefficient tables for the fused step kernel (``omg_fuse_cfg_step``).
+
+Replaces ``self.scheduler.set_timesteps / scale_model_input / step`` of the reference loop
+(/root/reference src/pipelines/lora_pipeline.py:390-392, :492, :615; third-party
+``diffusers==0.25.0`` ``scheduling_ddim`` / ``scheduling_euler_discrete``).  For epsilon prediction
+with eta = 0 both updates are linear in (sample, eps):
+
+    sample' = cx[i] * sample + ce[i] * eps ,   model_input = cin[i] * sample
+
+  DDIM : cx = sqrt(a_prev / a_t), ce = sqrt(1 - a_prev) - sqrt(a_prev (1 - a_t) / a_t), cin = 1
+  Euler: cx = 1,                  ce = sigma[i+1] - sigma[i],                       cin = 1/sqrt(sigma[i]^2 + 1)
+
+so the whole scheduler is a (n_steps, 4) fp32 table resident in HBM: row i = (cx_i, ce_i, cin_{i+1}, 0).
+The kernel indexes it with a device-side step counter, which is what makes the loop capturable
+as a hipGraph (no host read of ``t``).  Tables are computed in float64 on the host once.
+
+BASELINE.json names DDIM; the reference never sets a scheduler, so a stock SDXL-base checkpoint
+would run Euler — both are provided, DDIM is the benchmark default.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class _Base:
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 steps_offset: int = 1):
+        self.num_train_timesteps = num_train_timesteps
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=np.float64) ** 2
+        self.alphas_cumprod = np.cumprod(1.0 - betas)
+        self.steps_offset = steps_offset
+        self.timesteps = None
+        self.num_inference_steps = None
+
+    def _leading(self, n: int) -> np.ndarray:
+        ratio = self.num_train_timesteps // n
+        return (np.arange(0, n) * ratio).round()[::-1].astype(np.int64) + self.steps_offset
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        self._ts = self._leading(num_inference_steps)
+        self.timesteps = torch.from_numpy(self._ts.astype(np.float32 if self.float_timesteps else np.int64)).to(device)
+        self._build()
+
+    # (n,) float64 arrays filled by _build()
+    cx: np.ndarray
+    ce: np.ndarray
+    cin: np.ndarray
+
+    def coef_table(self, device) -> torch.Tensor:
+        n = self.num_inference_steps
+        tab = np.zeros((n, 4), dtype=np.float64)
+        tab[:, 0], tab[:, 1] = self.cx, self.ce
+        tab[:-1, 2] = self.cin[1:]
+        tab[-1, 2] = 1.0
+        return torch.from_numpy(tab.astype(np.float32)).to(device)
+
+    def cin0(self, device) -> torch.Tensor:
+        return torch.tensor([self.cin[0]], dtype=torch.float32, device=device)
+
+    def _index(self, t) -> int:
+        tv = float(t)
+        idx = np.nonzero(self._ts == int(round(tv)))[0]
+        if len(idx) == 0:
+            raise ValueError(f"timestep {tv} is not on the schedule")
+        return int(idx[0])
+
+    # diffusers-style per-step API (host-driven use outside the fused loop)
+    def scale_model_input(self, sample: torch.Tensor, t) -> torch.Tensor:
+        return sample * float(self.cin[self._index(t)])
+
+    def step(self, model_output: torch.Tensor, t, sample: torch.Tensor, return_dict: bool = False, **kw):
+        i = self._index(t)
+        prev = (float(self.cx[i]) * sample.float() + float(self.ce[i]) * model_output.float()).to(sample.dtype)
+        return (prev,)
+
+
+class DDIMScheduler(_Base):
+    float_timesteps = False
+    init_noise_sigma = 1.0
+
+    def _build(self):
+        n = self.num_inference_steps
+        ac = self.alphas_cumprod
+        ratio = self.num_train_timesteps // n
+        a_t = ac[self._ts]
+        prev = self._ts - ratio
+        a_p = np.where(prev >= 0, ac[np.clip(prev, 0, None)], ac[0])     # set_alpha_to_one = False
+        self.cx = np.sqrt(a_p / a_t)
+        self.ce = np.sqrt(1 - a_p) - np.sqrt(a_p * (1 - a_t) / a_t)
+        self.cin = np.ones(n)
+
+
+class EulerDiscreteScheduler(_Base):
+    float_timesteps = True
+
+    def _build(self):
+        n = self.num_inference_steps
+        ac = self.alphas_cumprod
+        sig_all = np.sqrt((1 - ac) / ac)
+        s = np.interp(self._ts.astype(np.float64), np.arange(self.num_train_timesteps), sig_all)
+        self.sigmas = np.concatenate([s, [0.0]])
+        self.init_noise_sigma = float(np.sqrt(self.sigmas.max() ** 2 + 1))   # "leading" spacing
+        self.cx = np.ones(n)
+        self.ce = self.sigmas[1:] - self.sigmas[:-1]
+        self.cin = 1.0 / np.sqrt(s ** 2 + 1)
+
+
+def make_scheduler(name: str):
+    return {"ddim": DDIMScheduler, "euler": EulerDiscreteScheduler}[name.lower()]()

@@ -155,11 +155,15 @@ def param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
 
 
 def init_state_dict(cfg: UNetConfig, seed: int = 0, dtype: torch.dtype = torch.float32,
-                    qk_gain: float = 2.0) -> Dict[str, Tensor]:
+                    qk_gain: float = 1.0) -> Dict[str, Tensor]:
     """Seeded synthetic weights (no SDXL checkpoint exists offline; SURVEY §8d recipe).
 
     Linear/conv ~ N(0, 1/fan_in); norms gamma ~ 1 + 0.1 N, beta ~ 0.1 N; to_q/to_k are scaled by
-    ``qk_gain`` so that softmax rows are peaked rather than near-uniform.
+    ``qk_gain`` (logit std ~ qk_gain^2).  The default 1.0 keeps the 40-layer random network
+    well-conditioned: at 2.0 the softmax rows are near one-hot and merely rounding q/k/v to fp16
+    INSIDE THIS ORACLE moves the output by 0.08 (measured), i.e. the comparison would test chaos,
+    not kernels.  Peaked / dominant-logit rows are exercised at kernel level instead
+    (tests/test_kernels_gpu.py::test_attention).
     Values are rounded through ``dtype`` so the product (fp16/bf16) and the oracle (fp32) see the
     same numbers.
     """
@@ -301,6 +305,8 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
         if taps is not None:
             taps[n] = v
 
+    tap("emb", emb)
+
     h = _conv(sd, "conv_in", sample)
     tap("conv_in", h)
     skips: List[Tensor] = [h]
@@ -308,9 +314,11 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
     for i, typ in enumerate(cfg.down_block_types):
         for j in range(cfg.layers_per_block):
             h = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", cfg, h, emb)
+            tap(f"down_blocks.{i}.resnets.{j}", h)
             if typ == "CrossAttnDownBlock2D":
                 h = transformer_2d(sd, f"down_blocks.{i}.attentions.{j}", cfg, cfg.attention_head_dim[i],
                                    cfg.transformer_layers_per_block[i], h, ctx, attn_fn, lora)
+                tap(f"down_blocks.{i}.attentions.{j}", h)
             skips.append(h)
         if i != nblocks - 1:
             h = _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2)
@@ -319,8 +327,10 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
     if down_block_additional_residuals is not None:
         skips = [s + r.float() for s, r in zip(skips, down_block_additional_residuals)]
     h = resnet_block(sd, "mid_block.resnets.0", cfg, h, emb)
+    tap("mid_block.resnets.0", h)
     h = transformer_2d(sd, "mid_block.attentions.0", cfg, cfg.attention_head_dim[-1],
                        cfg.transformer_layers_per_block[-1], h, ctx, attn_fn, lora)
+    tap("mid_block.attentions.0", h)
     h = resnet_block(sd, "mid_block.resnets.1", cfg, h, emb)
     if mid_block_additional_residual is not None:
         h = h + mid_block_additional_residual.float()
@@ -331,9 +341,11 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
         for j in range(cfg.layers_per_block + 1):
             h = torch.cat([h, skips.pop()], dim=1)
             h = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", cfg, h, emb)
+            tap(f"up_blocks.{i}.resnets.{j}", h)
             if typ == "CrossAttnUpBlock2D":
                 h = transformer_2d(sd, f"up_blocks.{i}.attentions.{j}", cfg, rev_heads[i], rev_layers[i], h, ctx,
                                    attn_fn, lora)
+                tap(f"up_blocks.{i}.attentions.{j}", h)
         if i != nblocks - 1:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", h)
