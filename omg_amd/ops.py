@@ -38,6 +38,42 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+class KernelProfiler:
+    """Opt-in per-launch timing with HIP events on the launch stream (used by bench.py's roofline leg).
+    Off by default: the product path records nothing."""
+
+    def __init__(self):
+        self.records = []   # (kind, flops, start_event, end_event)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, kind: str, flops: float, start) -> None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.append((kind, flops, start, e))
+
+    def summary(self):
+        """kind -> dict(launches, ms, flops); call after torch.cuda.synchronize()."""
+        out = {}
+        for kind, fl, s, e in self.records:
+            d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+        return out
+
+
+_PROF: Optional[KernelProfiler] = None
+
+
+def set_profiler(p: Optional[KernelProfiler]) -> None:
+    global _PROF
+    _PROF = p
+
+
 class LoraSpec:
     """Second K-segment of a GEMM: ``C += A2 @ W2[adapter]^T`` (PEFT ``s * B(A(x))``)."""
 
@@ -105,6 +141,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     args.act = act
     args.out_scale = out_scale
     args.C, args.ldc = out.data_ptr(), out.stride(0)
+    if _PROF is not None:
+        t0 = _PROF.begin()
+        L.check(L.lib().omg_gemm(C.byref(args), _stream()), "omg_gemm")
+        _PROF.end("gemm", 2.0 * M * N * (K + args.K2), t0)
+        return out
     L.check(L.lib().omg_gemm(C.byref(args), _stream()), "omg_gemm")
     return out
 
@@ -141,6 +182,11 @@ def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, up
         a.residual = residual.data_ptr()
     a.out_scale = out_scale
     a.Y = y.data_ptr()
+    if _PROF is not None:
+        t0 = _PROF.begin()
+        L.check(L.lib().omg_conv2d(C.byref(a), _stream()), "omg_conv2d")
+        _PROF.end("gemm", 2.0 * B * Hout * Wout * Cout * ksize * ksize * (C1 + C2), t0)
+        return y
     L.check(L.lib().omg_conv2d(C.byref(a), _stream()), "omg_conv2d")
     return y
 
@@ -188,6 +234,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
     if out is None:
         out = torch.empty((B, Nq, heads * 64), dtype=q.dtype, device=q.device)
     a = _attn_args(q, k, vt, heads, k.shape[1], scale, qk_src, out, accumulate, out_scale)
+    if _PROF is not None:
+        t0 = _PROF.begin()
+        L.check(L.lib().omg_attn_fwd(C.byref(a), _stream()), "omg_attn_fwd")
+        _PROF.end("attn", 4.0 * B * heads * Nq * k.shape[1] * 64, t0)
+        return out
     L.check(L.lib().omg_attn_fwd(C.byref(a), _stream()), "omg_attn_fwd")
     return out
 
