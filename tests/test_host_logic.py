@@ -1,0 +1,126 @@
+"""CPU tests (-m "not gpu"): host-side logic of the product — controller drop-in vs the reference-generated
+golden vectors, scheduler coefficient tables vs the oracle schedulers, weight packing, sharding arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from omg_amd import controller as pc
+from omg_amd import ops, parallel
+from omg_amd.schedulers import DDIMScheduler, EulerDiscreteScheduler
+from oracle import controller as oc
+from oracle import schedulers as osched
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+P = "a man and a woman walking on the street"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "controller_golden.npz"))
+
+
+def cli_controller():
+    return pc.AttentionReplace([P, P], 50, cross_replace_steps={"default_": 1.0}, self_replace_steps=0.4, width=32, height=32,
+                               tokenizer=None, device="cpu", dtype=torch.float32)
+
+
+def test_controller_construction_matches_reference(gold):
+    c = cli_controller()
+    assert np.array_equal(c.mapper.numpy(), gold["t1_mapper"])
+    assert np.array_equal(c.cross_replace_alpha.numpy(), gold["t1_alpha"])
+    assert c.num_self_replace == tuple(gold["t1_num_self_replace"]) and c.batch_size == int(gold["t1_batch_size"])
+    assert c.is_pure_replacement and c.num_att_layers == -1 and (c.cur_step, c.cur_att_layer) == (0, 0)
+
+
+@pytest.mark.parametrize("name,is_cross,step", [("cross_q64", True, 0), ("self_q1024_s0", False, 0), ("self_q1056_s0", False, 0),
+                                                  ("self_q1024_s19", False, 19), ("self_q1024_s20", False, 20)])
+def test_controller_protocol_call_bitwise(gold, name, is_cross, step):
+    c = cli_controller()
+    c.num_att_layers = 4
+    c.cur_step = step
+    x = torch.from_numpy(gold[name + "_in"].copy())
+    y = c(x, is_cross, "down")
+    assert y is x and np.array_equal(y.numpy(), gold[name + "_out"])
+    # the fused path must make the same decision as the probability edit
+    c2 = cli_controller(); c2.num_att_layers = 4; c2.cur_step = step
+    src = c2.fused_qk_src(is_cross, x.shape[1], 4, "down", device="cpu")
+    changed = not np.array_equal(gold[name + "_in"], gold[name + "_out"])
+    assert (src is not None) == changed
+    if src is not None:
+        assert src.tolist() == [0, 1, 2, 2]
+    assert (c2.cur_step, c2.cur_att_layer) == (c.cur_step, c.cur_att_layer)
+
+
+def test_controller_counters_and_reset(gold):
+    c = cli_controller()
+    c.num_att_layers = 140
+    for _ in range(140):
+        c.fused_qk_src(True, 4096, 4, "mid", device="cpu")
+    assert [c.cur_step, c.cur_att_layer] == list(gold["t5_counters"])
+    c.reset()
+    assert (c.cur_step, c.cur_att_layer) == (0, 0)
+    with pytest.raises(ValueError):
+        c.fused_qk_src(True, 64, 6, "down", device="cpu")     # batch must be 2 * len(prompts)
+
+
+def test_controller_general_mapper_matches_reference(gold):
+    prompts = ["a man on the road", "a woman on the road"]
+    c = pc.AttentionReplace(prompts, 10, {"default_": 0.6, "road": (0.2, 0.9)}, (0.1, 0.5), 4, 4, tokenizer=oc.PieceTokenizer(),
+                            device="cpu", dtype=torch.float32)
+    assert np.array_equal(c.mapper.numpy(), gold["gen_mapper"]) and np.array_equal(c.cross_replace_alpha.numpy(), gold["gen_alpha"])
+    assert not c.is_pure_replacement
+    with pytest.raises(RuntimeError):
+        c.fused_qk_src(True, 16, 4)
+    c.num_att_layers = 2
+    for step in (0, 3, 7):
+        for kind in ("cross", "self"):
+            c.reset(); c.cur_step = step
+            key = f"gen_s{step}_{kind}"
+            y = c(torch.from_numpy(gold[key + "_in"].copy()), kind == "cross", "mid")
+            np.testing.assert_allclose(y.numpy(), gold[key + "_out"], rtol=0, atol=1e-7)
+    assert np.array_equal(pc.get_replacement_mapper(["a man on the street", "a dog on the street"], oc.WhitespaceTokenizer()).numpy(),
+                          gold["t6_mapper_swap"])
+    with pytest.raises(ValueError):
+        pc.get_replacement_mapper(["a man", "a man walking"], oc.WhitespaceTokenizer())
+
+
+@pytest.mark.parametrize("n", [50, 30, 10])
+def test_scheduler_tables_reproduce_the_oracle_schedulers(n):
+    rng = np.random.default_rng(0)
+    for mine, ref in ((DDIMScheduler(), osched.DDIM(n)), (EulerDiscreteScheduler(), osched.EulerDiscrete(n))):
+        mine.set_timesteps(n, device="cpu")
+        assert np.array_equal(np.asarray(mine.timesteps.numpy(), dtype=np.float64), np.asarray(ref.timesteps, dtype=np.float64))
+        assert abs(mine.init_noise_sigma - ref.init_noise_sigma) < 1e-12
+        tab = mine.coef_table("cpu").double().numpy()
+        x = rng.standard_normal(16)
+        for i in range(n):
+            eps = rng.standard_normal(16)
+            want = ref.step(eps, i, x)
+            got = tab[i, 0] * x + tab[i, 1] * eps
+            np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(mine.cin[i] * x, ref.scale_model_input(x, i), rtol=1e-12)
+            if i + 1 < n:
+                np.testing.assert_allclose(tab[i, 2], mine.cin[i + 1], rtol=1e-6)
+            t = mine.timesteps[i]
+            np.testing.assert_allclose(mine.step(torch.from_numpy(eps), t, torch.from_numpy(x))[0].numpy(), want, rtol=2e-6, atol=2e-6)  # fp32 inside
+            x = want
+
+
+def test_weight_packing_layouts():
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = ops.pack_conv_weight(w)
+    assert p.shape == (2, 27) and p[1, (2 * 3 + 1) * 3 + 2] == w[1, 2, 2, 1]      # [co][ky][kx][ci]
+    perm = ops.geglu_row_perm(256)
+    assert sorted(perm.tolist()) == list(range(256))
+    assert perm[:32].tolist() == list(range(32)) and perm[32:64].tolist() == list(range(128, 160)) and perm[64] == 32
+
+
+def test_shard_indices_cover_everything_once():
+    for n in (1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            seen = sum((parallel.shard_indices(n, r, world) for r in range(world)), [])
+            assert seen == list(range(n))
+            sizes = [len(parallel.shard_indices(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,85 @@
+"""CPU tests (-m "not gpu"): repository contracts — the C-ABI library loads and exports every symbol that
+include/omg_hip.h declares, the product never imports the oracle, and the product refuses to compute on CPU."""
+import ast
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "omg_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(omg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from omg_amd import _lib
+    lib = _lib.lib()                       # raises if libomg_hip.so is missing or stale
+    declared = header_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/omg_hip.h but not exported"
+        assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in omg_amd/_lib.py"
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", nm), f"{name} is not a defined text symbol"
+    assert lib.omg_abi_version() == 1
+
+
+def test_struct_sizes_match_the_header():
+    """ctypes mirrors must have the size the C compiler gives the structs."""
+    import ctypes
+    from omg_amd import _lib
+    code = '#include <stdio.h>\n#include "omg_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(omg_gemm_args),sizeof(omg_conv2d_args),sizeof(omg_attn_args),sizeof(omg_step_args));return 0;}'
+    exe = os.path.join(ROOT, "tests", "_sizes.out")
+    subprocess.run(["gcc", "-x", "c", "-I", os.path.join(ROOT, "include"), "-o", exe, "-"], input=code.encode(), check=True)
+    try:
+        out = subprocess.check_output([exe], text=True).split()
+    finally:
+        os.remove(exe)
+    got = [ctypes.sizeof(c) for c in (_lib.GemmArgs, _lib.Conv2dArgs, _lib.AttnArgs, _lib.StepArgs)]
+    assert got == [int(v) for v in out]
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "omg_amd")):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(dirpath, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, f"product files import the oracle: {bad}"
+
+
+def test_no_cpu_fallback():
+    from omg_amd import _lib, ops
+    x = torch.zeros(8, 8, dtype=torch.float16)
+    with pytest.raises(_lib.OmgHipError):
+        ops.gemm(x, x)
+    with pytest.raises(_lib.OmgHipError):
+        ops.layernorm(x, x[0], x[0], 1e-5)
+    from omg_amd.unet import UNet2DConditionModel, UNetConfig
+    u = UNet2DConditionModel(UNetConfig.tiny(), device="meta")
+    with pytest.raises(_lib.OmgHipError):
+        u(torch.zeros(1, 4, 16, 16), 1, encoder_hidden_states=torch.zeros(1, 77, 128))
+
+
+def test_reference_is_not_needed_at_runtime():
+    """Nothing under omg_amd/, bench.py or __graft_entry__.py may read /root/reference (absent on the GPU box)."""
+    for path in ["bench.py", "__graft_entry__.py"] + [os.path.join("omg_amd", f) for f in os.listdir(os.path.join(ROOT, "omg_amd")) if f.endswith(".py")]:
+        src = open(os.path.join(ROOT, path)).read()
+        code = "\n".join(l for l in src.splitlines() if "sys.path" in l or "open(" in l or "import " in l)
+        assert "/root/reference" not in code, path
