@@ -87,6 +87,7 @@ SYMBOLS = {
     "omg_attn_probs": (c_i32, [C.POINTER(AttnArgs), c_vp, c_vp]),
     "omg_attn_apply_probs": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "omg_debug_set_glds": (None, [c_i32]),
+    "omg_debug_set_gemm_variant": (None, [c_i32]),
 }
 
 _lib = None
@@ -119,6 +120,9 @@ def lib() -> C.CDLL:
         fn.argtypes = args
     if l.omg_abi_version() != 1:
         raise OmgHipError("libomg_hip.so ABI version mismatch; rebuild")
+    v = os.environ.get("OMG_GEMM_VARIANT")      # debugging/benchmarking aid: force one GEMM tile configuration
+    if v:
+        l.omg_debug_set_gemm_variant(int(v))
     _lib = l
     return l
 

@@ -62,6 +62,95 @@ OMG_DEV void stage16(const char* src, char* lds_wave_base, int lane, u32x4& hold
   }
 }
 
+template <typename T>
+OMG_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], char* smem, int w, int lane, int m0, int n0, int m_end) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm = w >> 1, wn = w & 1;
+  // ---------------- epilogue: acc -> LDS (fp32) -> coalesced 16-B rows
+  __syncthreads();
+  float* stage = (float*)smem + w * (64 * STAGE_LD);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  const int wm0 = m0 + wm * 64;
+  const int wn0 = n0 + wn * 64;
+  if (p.act == OMG_ACT_GEGLU) {
+    // wave tile columns = [32 value | 32 gate]; 4 lanes per row, 16 rows per pass
+    const int ocol0 = (wn0 >> 1);
+    const int sub = lane & 3, rsub = lane >> 2;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 16 + rsub;
+      const int gm = wm0 + row;
+      const int gc = wn0 + sub * 8;          // packed column of the value half
+      if (gm < m_end && gc < p.N) {
+        float v[8], g[8], bv[8], bg[8];
+        const float* sp = stage + row * STAGE_LD + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
+        if (p.bias) {
+          unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+          unpack8<T>(*(const u32x4*)(p.bias + (long)(gc + 32) * 2), bg);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] += bv[e]; g[e] += bg[e]; }
+        }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
+        *(u32x4*)(p.C + ((long)gm * p.ldc + ocol0 + sub * 8) * 2) = pack8<T>(o);
+      }
+    }
+    return;
+  }
+  {
+    const int sub = lane & 7, rsub = lane >> 3;
+    const int gc = wn0 + sub * 8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + rsub;
+      const int gm = wm0 + row;
+      if (gm < m_end && gc < p.N) {
+        float v[8];
+        const float* sp = stage + row * STAGE_LD + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
+        if (p.group_bias) {
+          float gb[8];
+          const int g = gm / p.rows_per_group;
+          unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += gb[e];
+        }
+        if (p.act == OMG_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+        if (p.residual) {
+          float rv[8];
+          unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+        }
+        *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
+      }
+    }
+  }
+}
+
 template <typename T, bool CONV, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,95 +307,351 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
     if constexpr (!GLDS) { if (kt + 1 < nk) commit(buf ^ 1); }
   }
 
-  // ---------------- epilogue: acc -> LDS (fp32) -> coalesced 16-B rows
-  __syncthreads();
-  float* stage = (float*)smem + w * (64 * STAGE_LD);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
-      }
-  __syncthreads();
+  gemm_epilogue<T>(p, acc, smem, w, lane, m0, n0, m_end);
+}
 
-  const int wm0 = m0 + wm * 64;
-  const int wn0 = n0 + wn * 64;
-  if (p.act == OMG_ACT_GEGLU) {
-    // wave tile columns = [32 value | 32 gate]; 4 lanes per row, 16 rows per pass
-    const int ocol0 = (wn0 >> 1);
-    const int sub = lane & 3, rsub = lane >> 2;
+
+// ------------------------------------------------------------------------------------------------
+// v3: large-tile, deep-ring variant.  L2 -> LDS traffic is what bounds the 128x128 tile on MI355X
+// (64 FLOP per staged byte: ~12 TB/s of LDS-DMA at 770 TF/s), so v3 raises the block tile to 256x256
+// (128 FLOP/B) or 256x128 and keeps the wave tile N at 64 (so the GEGLU value|gate pairing and the
+// row-coalesced epilogue are unchanged).  BK = 32 stages in a 4-deep LDS ring filled by LDS-DMA three
+// stages ahead; ONE raw s_barrier per stage; COUNTED vmcnt (never 0 in steady state) so two stages stay
+// in flight across the barrier (cdna guide §5 "Pipelining across barriers").
+//   BM x BN   waves (M x N)  wave tile   threads  LDS ring      blocks/CU
+//   256x256   2 x 4          128 x 64    512      4 x 32 KiB    1
+//   256x128   4 x 2           64 x 64    512      4 x 24 KiB    1
+// LDS image per stage: rows of 64 B (4 chunks of 16 B), chunk ^= (row >> 2) & 3 (16 lanes of a
+// ds_read_b128 group -> 16 distinct slots); applied on the DMA source side and on the read (rule 21).
+constexpr int BK3 = 32;
+constexpr int NST3 = 4;
+
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
+__global__ __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_) / 4) void gemm_kernel_v3(GemmP p) {
+  constexpr int NW = WM_ * WN_;
+  constexpr int MT = BM_ / WM_ / 32;             // 32-row MFMA tiles per wave (2 or 4)
+  constexpr int NT = BN_ / WN_ / 32;             // must be 2
+  static_assert(NT == 2, "wave tile N must be 64");
+  constexpr int A_BYTES = BM_ * BK3 * 2;
+  constexpr int STAGE_BYTES = (BM_ + BN_) * BK3 * 2;
+  constexpr int A_INSTR = BM_ / 16 / NW;         // DMA instructions per wave per stage for A
+  constexpr int B_INSTR = BN_ / 16 / NW;
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
+  constexpr int NDMA = A_INSTR + B_INSTR;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_per_group = p.tiles_m * p.tiles_n;
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  const int tm = t_in % p.tiles_m;
+  const int tn = t_in / p.tiles_m;
+  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
+  const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
+  const int m0 = m_base + tm * BM_;
+  const int n0 = tn * BN_;
+
+  int adapter = 0;
+  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
+  const bool seg2 = (p.K2 > 0) && (adapter >= 0);
+  if (p.w_adapter_stride != 0 && adapter < 0) return;
+  const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
+  const char* W2p = p.W2 + (seg2 ? (long)adapter * p.w2_adapter_stride * 2 : 0);
+  const int a2off = (p.a2_col_block > 0) ? (n0 / p.a2_col_block) * p.K2 : 0;
+
+  const int nk1 = (p.K + BK3 - 1) / BK3;
+  const int nk2 = seg2 ? (p.K2 + BK3 - 1) / BK3 : 0;
+  const int nk = nk1 + nk2;
+
+  // ---- staging coordinates.  DMA instruction j of an operand covers rows [j*16, j*16+16); wave w issues
+  // instructions j = w + i*NW.  lane -> (row = lane>>2, 16-B position = lane&3).
+  const int prow = lane >> 2;
+  const int ppos = lane & 3;
+  const char* zero = (const char*)omg_zero_page;
+  const char* a_ptr[A_INSTR];      // plain GEMM: row base of A (segment 1) incl. source chunk
+  const char* a2_ptr[A_INSTR];
+  const char* w_ptr[B_INSTR];
+  const char* w2_ptr[B_INSTR];
+  int a_chunk[A_INSTR], w_chunk[B_INSTR];
+  int cb[A_INSTR], cy[A_INSTR], cx[A_INSTR];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 16 + rsub;
-      const int gm = wm0 + row;
-      const int gc = wn0 + sub * 8;          // packed column of the value half
-      if (gm < m_end && gc < p.N) {
-        float v[8], g[8], bv[8], bg[8];
-        const float* sp = stage + row * STAGE_LD + sub * 8;
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int r = (w + i * NW) * 16 + prow;
+    int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
+    const int c = ppos ^ ((r >> 2) & 3);
+    a_chunk[i] = c;
+    if constexpr (CONV) {
+      const int hw = p.Hout * p.Wout;
+      const int b = gm / hw; const int rem = gm - b * hw;
+      cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;
+      a_ptr[i] = nullptr; a2_ptr[i] = nullptr;
+    } else {
+      a_ptr[i] = p.A + ((long)gm * p.lda + c * 8) * 2;
+      a2_ptr[i] = p.A2 ? p.A2 + ((long)gm * p.lda2 + a2off + c * 8) * 2 : nullptr;
+    }
+  }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
-        if (p.bias) {
-          unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
-          unpack8<T>(*(const u32x4*)(p.bias + (long)(gc + 32) * 2), bg);
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int r = (w + i * NW) * 16 + prow;
+    int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
+    const int c = ppos ^ ((r >> 2) & 3);
+    w_chunk[i] = c;
+    w_ptr[i] = Wp + ((long)gn * p.ldw + c * 8) * 2;
+    w2_ptr[i] = p.W2 ? W2p + ((long)gn * p.ldw2 + c * 8) * 2 : nullptr;
+  }
+  const int Ctot = p.C1 + p.C2;
+  const int cpt = CONV ? Ctot / BK3 : 1;
+  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
+
+  auto issue = [&](int kt) {
+    char* sbase = smem + (kt & (NST3 - 1)) * STAGE_BYTES;
+    const bool s2 = kt >= nk1;
+    const int k0 = (s2 ? kt - nk1 : kt) * BK3;
+    const int Kseg = s2 ? p.K2 : p.K;
+    const bool full = (k0 + BK3) <= Kseg;              // wave-uniform: no per-lane K-tail test needed
+    if constexpr (CONV) {
+      const int tap = kt / cpt; const int cc = kt - tap * cpt;
+      const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
+      int c0 = cc * BK3;
+      const char* xsrc = p.A; int xC = p.C1;
+      if (c0 >= p.C1) { xsrc = p.X2; xC = p.C2; c0 -= p.C1; }
+      const int Hl = p.upsample ? p.Hin * 2 : p.Hin;
+      const int Wl = p.upsample ? p.Win * 2 : p.Win;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { v[e] += bv[e]; g[e] += bg[e]; }
-        }
-        float o[8];
+      for (int i = 0; i < A_INSTR; ++i) {
+        int iy = cy[i] * p.stride + dy - pad;
+        int ix = cx[i] * p.stride + dx - pad;
+        const bool ok = (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
+        if (p.upsample) { iy >>= 1; ix >>= 1; }
+        const long pix = ((long)cb[i] * p.Hin + iy) * p.Win + ix;
+        const char* asrc = ok ? xsrc + (pix * xC + c0 + a_chunk[i] * 8) * 2 : zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
-        *(u32x4*)(p.C + ((long)gm * p.ldc + ocol0 + sub * 8) * 2) = pack8<T>(o);
+      for (int i = 0; i < B_INSTR; ++i) {
+        const char* wsrc = w_ptr[i] + (long)kt * (BK3 * 2);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const char* asrc = (s2 ? a2_ptr[i] : a_ptr[i]) + k0 * 2;
+        if (!full && (k0 + a_chunk[i] * 8) >= Kseg) asrc = zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_INSTR; ++i) {
+        const char* wsrc = (s2 ? w2_ptr[i] : w_ptr[i]) + k0 * 2;
+        if (!full && (k0 + w_chunk[i] * 8) >= Kseg) wsrc = zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
       }
     }
-    return;
+  };
+
+  const int wm = w / WN_, wn = w % WN_;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  using V8 = typename Vec<T>::v8;
+
+  // stage-relative fragment offsets (ks = 0/1 differ by chunk ^ 2 -> precompute both)
+  int aro[MT][2], bro[NT][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int kc = ks * 2 + hi;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ra = wm * (MT * 32) + i * 32 + l31;
+      aro[i][ks] = ra * 64 + ((kc ^ ((ra >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int rb = wn * 64 + j * 32 + l31;
+      bro[j][ks] = A_BYTES + rb * 64 + ((kc ^ ((rb >> 2) & 3)) << 4);
+    }
   }
-  {
-    const int sub = lane & 7, rsub = lane >> 3;
-    const int gc = wn0 + sub * 8;
-    float bv[8];
+
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-    if (p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+  for (int s = 0; s < NST3 - 1; ++s)
+    if (s < nk) issue(s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;         // stages still in flight behind stage kt (max 2)
+    if (ahead >= 2) {
+      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (ahead == 1) {
+      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NST3 - 1 < nk) issue(kt + NST3 - 1);
+    const char* sb = smem + (kt & (NST3 - 1)) * STAGE_BYTES;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + rsub;
-      const int gm = wm0 + row;
-      if (gm < m_end && gc < p.N) {
-        float v[8];
-        const float* sp = stage + row * STAGE_LD + sub * 8;
+    for (int ks = 0; ks < 2; ++ks) {
+      V8 af[MT], bf[NT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
-        if (p.group_bias) {
-          float gb[8];
-          const int g = gm / p.rows_per_group;
-          unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
+      for (int j = 0; j < NT; ++j) bf[j] = *(const V8*)(sb + bro[j][ks]);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += gb[e];
+      for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + aro[i][ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[i], bf[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue: one 32-row slab of every wave per pass through a [32][STAGE_LD] fp32 staging area
+  const int wm0 = m0 + wm * (MT * 32);
+  const int wn0 = n0 + wn * 64;
+  float* stage = (float*)smem + w * (32 * STAGE_LD);
+  const int sub = lane & 7, rsub = lane >> 3;
+  const int gc = wn0 + sub * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+  const bool geglu = p.act == OMG_ACT_GEGLU;
+  if (!geglu && p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
+      }
+    __syncthreads();
+    if (geglu) {
+      const int s4 = lane & 3, r4 = lane >> 2;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + r4;
+        const int gm = wm0 + i * 32 + row;
+        const int gcc = wn0 + s4 * 8;
+        if (gm < m_end && gcc < p.N) {
+          float v[8], g[8];
+          const float* sp = stage + row * STAGE_LD + s4 * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
+          if (p.bias) {
+            float b1[8], b2[8];
+            unpack8<T>(*(const u32x4*)(p.bias + (long)gcc * 2), b1);
+            unpack8<T>(*(const u32x4*)(p.bias + (long)(gcc + 32) * 2), b2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] += b1[e]; g[e] += b2[e]; }
+          }
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
+          *(u32x4*)(p.C + ((long)gm * p.ldc + (wn0 >> 1) + s4 * 8) * 2) = pack8<T>(o);
         }
-        if (p.act == OMG_ACT_SILU) {
+      }
+    } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rsub;
+        const int gm = wm0 + i * 32 + row;
+        if (gm < m_end && gc < p.N) {
+          float v[8];
+          const float* sp = stage + row * STAGE_LD + sub * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
+          if (p.group_bias) {
+            float gb[8];
+            const int g = gm / p.rows_per_group;
+            unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += gb[e];
+          }
+          if (p.act == OMG_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+          if (p.residual) {
+            float rv[8];
+            unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-        if (p.residual) {
-          float rv[8];
-          unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
       }
     }
   }
 }
 
+constexpr int lds_bytes_v3(int bm, int bn, int nw) {
+  const int ring = NST3 * (bm + bn) * BK3 * 2;
+  const int epi = nw * 32 * STAGE_LD * 4;
+  return ring > epi ? ring : epi;
+}
+
+
+
 bool g_use_glds = true;
+int g_variant = 0;   // 0 = heuristic, 1 = 128x128 v1, 3 = 256x256, 4 = 256x128
+
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
+int launch_v3(GemmP p, hipStream_t s, int mrows) {
+  constexpr int lds = lds_bytes_v3(BM_, BN_, WM_ * WN_);
+  static bool attr = false;
+  if (!attr) {
+    attr = true;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  p.tiles_m = (mrows + BM_ - 1) / BM_;
+  p.tiles_n = (p.N + BN_ - 1) / BN_;
+  const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
+  if (grid <= 0) return OMG_OK;
+  OMG_LAUNCH((gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
+  return omg_check_launch("gemm_v3");
+}
+
+// tile choice: estimated time = rounds x per-tile time, where the per-tile time is (tile FLOPs) / (relative
+// MFMA rate of the configuration); 256x256 runs ~1.5x the rate of 128x128 once the grid fills the chip.
+int choose_variant(int mrows, int groups, int N) {
+  if (g_variant != 0) return g_variant;
+  const long t128 = (long)groups * ((mrows + 127) / 128) * ((N + 127) / 128);
+  const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
+  const long t256x128 = (long)groups * ((mrows + 255) / 256) * ((N + 127) / 128);
+  const double r128 = (double)((t128 + 511) / 512) * 2.0 * 1.0 / 1.0;         // 2 blocks/CU resident -> rounds of 512
+  const double e128 = r128 * 1.0;
+  const double e256 = (double)((t256 + 255) / 256) * 4.0 / 1.5;
+  const double e256x128 = (double)((t256x128 + 255) / 256) * 2.0 / 1.25;
+  if (e256 <= e128 && e256 <= e256x128) return 3;
+  if (e256x128 <= e128) return 4;
+  return 1;
+}
 
 template <typename T, bool CONV>
 int launch(const GemmP& p, hipStream_t s) {
+  const int mrows = p.tile_groups > 1 ? p.rows_per_group : p.M;
+  if (g_use_glds) {
+    const int v = choose_variant(mrows, p.tile_groups, p.N);
+    if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4>(p, s, mrows);
+    if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2>(p, s, mrows);
+  }
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
   if (g_use_glds) {
@@ -335,6 +680,7 @@ void ensure_attrs() {
 }  // namespace
 
 extern "C" void omg_debug_set_glds(int on) { g_use_glds = on != 0; }
+extern "C" void omg_debug_set_gemm_variant(int v) { g_variant = v; }
 
 extern "C" int omg_gemm(const omg_gemm_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_gemm: null args");

@@ -27,17 +27,19 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--glds", type=int, default=1)
     ap.add_argument("--only", default="")
+    ap.add_argument("--variant", type=int, default=0)
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     dev = torch.device("cuda:0")
     L.lib().omg_debug_set_glds(a.glds)
+    L.lib().omg_debug_set_gemm_variant(a.variant)
     R = lambda *s: torch.randn(*s, device=dev, dtype=dt)
-    print(f"# dtype={a.dtype} glds={a.glds}")
+    print(f"# dtype={a.dtype} glds={a.glds} variant={a.variant}")
     if not a.only or "gemm" in a.only:
         for (M, N, K, tag) in [(16384, 640, 640, "64^2 proj B4"), (16384, 1920, 640, "64^2 qkv B4"), (16384, 5120, 640, "64^2 geglu B4"),
                                (16384, 640, 2560, "64^2 ffout B4"), (4096, 1280, 1280, "32^2 proj B4"), (4096, 3840, 1280, "32^2 qkv B4"),
                                (4096, 10240, 1280, "32^2 geglu B4"), (4096, 1280, 5120, "32^2 ffout B4"), (2048, 1280, 1280, "32^2 proj B2"),
-                               (2048, 10240, 1280, "32^2 geglu B2"), (2048, 1280, 5120, "32^2 ffout B2"), (8192, 8192, 8192, "square 8k"),
+                               (2048, 10240, 1280, "32^2 geglu B2"), (2048, 1280, 5120, "32^2 ffout B2"), (8192, 1280, 1280, "32^2 proj B8"), (8192, 1280, 5120, "32^2 ffout B8"), (8192, 3840, 1280, "32^2 qkv B8"), (8192, 10240, 1280, "32^2 geglu B8"), (32768, 1280, 1280, "32^2 proj B32"), (8192, 8192, 8192, "square 8k"),
                                (4096, 4096, 4096, "square 4k")]:
             x, w = R(M, K), R(N, K)
             out = torch.empty(M, N, device=dev, dtype=dt)
