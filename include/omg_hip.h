@@ -170,12 +170,14 @@ int omg_layernorm(int dtype, const void* X, int64_t ldx, int M, int C, float eps
 
 /* ------------------------------------------------------------------------
  * Boundary convolutions (NCHW latents <-> NHWC features).
- * conv_in : UNet2DConditionModel.conv_in  (4 -> C0, 3x3), input NCHW fp32|T.
+ * conv_in : UNet2DConditionModel.conv_in  (4 -> C0, 3x3), input NCHW fp32|T; executed as a 64-column
+ *           im2col + the MFMA GEMM (K = 36 padded to one 64-wide slice).
  * conv_out: UNet2DConditionModel.conv_out (C0 -> 4, 3x3) on the already
  *           normalised+SiLU'd NHWC features, output NCHW in fp32.
  * ---------------------------------------------------------------------- */
 int omg_conv_in(int dtype, const void* X_nchw, int x_is_f32, int B, int Cin, int H, int W,
-                const void* Wt /*[Cout][3][3][Cin]*/, const void* bias, int Cout,
+                const void* Wt /*[Cout][64]: (ky,kx,ci) order, zero padded to 64 columns*/, const void* bias, int Cout,
+                void* workspace /* B*H*W*64 elements of dtype: im2col patches */,
                 void* Y_nhwc, void* stream);
 int omg_conv_out(int dtype, const void* X_nhwc, int B, int H, int W, int Cin,
                  const void* Wt /*[Cout][3][3][Cin]*/, const void* bias, int Cout,

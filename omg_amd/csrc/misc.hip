@@ -11,41 +11,27 @@ extern "C" int omg_abi_version(void) { return OMG_ABI_VERSION; }
 namespace {
 
 // ---------------------------------------------------------------- conv_in
-// out[b,y,x,co] = bias[co] + sum_{ky,kx,ci} w[co][ky][kx][ci] * in[b,ci,y+ky-1,x+kx-1]
-// thread -> (pixel, 8 output channels); weights [Cout][9*Cin] staged in LDS as fp32.
+// conv_in (Cin = 4, 3x3) as im2col + the MFMA GEMM: patch[pix][(ky*3+kx)*Cin + ci], zero padded to KP (64)
+// columns so that it is one BK slice of omg_gemm.  One thread per pixel: 36 coalesced NCHW reads
+// (neighbouring threads = neighbouring x), 128 B written as 8 x 16 B.
 template <typename T, typename TI>
-__global__ __launch_bounds__(256) void conv_in_kernel(const TI* X, int B, int Cin, int H, int W, const T* Wt, const T* bias,
-                                                       int Cout, char* Y) {
-  extern __shared__ float wl[];   // [Cout][9*Cin]
-  const int K = 9 * Cin;
-  for (int i = threadIdx.x; i < Cout * K; i += 256) wl[i] = (float)Wt[i];
-  __syncthreads();
-  const int nvec = Cout / 8;
-  const int ppb = 256 / nvec;                 // pixels per block pass
-  const int pl = threadIdx.x / nvec, vec = threadIdx.x - pl * nvec;
-  if (pl >= ppb) return;
+__global__ __launch_bounds__(256) void im2col_in_kernel(const TI* X, int B, int Cin, int H, int W, int KP, char* out) {
   const long npix = (long)B * H * W;
-  for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += (long)gridDim.x * blockDim.x) {
     const int b = (int)(pix / (H * W)); const int rem = (int)(pix - (long)b * H * W);
     const int y = rem / W, x = rem - y * W;
-    float acc[8];
+    for (int c8 = 0; c8 < KP / 8; ++c8) {
+      float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bias ? (float)bias[vec * 8 + e] : 0.f;
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = y + ky - 1;
-      if (iy < 0 || iy >= H) continue;
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = x + kx - 1;
-        if (ix < 0 || ix >= W) continue;
-        for (int ci = 0; ci < Cin; ++ci) {
-          const float v = (float)X[(((long)b * Cin + ci) * H + iy) * W + ix];
-          const int k = (ky * 3 + kx) * Cin + ci;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] += v * wl[(vec * 8 + e) * K + k];
-        }
+      for (int e = 0; e < 8; ++e) {
+        const int k = c8 * 8 + e;
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+        const bool ok = (tap < 9) && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        f[e] = ok ? (float)X[(((long)b * Cin + ci) * H + iy) * W + ix] : 0.f;
       }
+      *(u32x4*)(out + (pix * KP + c8 * 8) * 2) = pack8<T>(f);
     }
-    *(u32x4*)(Y + (pix * Cout + vec * 8) * 2) = pack8<T>(acc);
   }
 }
 
@@ -163,13 +149,15 @@ __global__ __launch_bounds__(256) void step_kernel(StepP p) {
       cnd1 = (any ? 0.f : cnd1) + add_c;
       if (p.fused_out) { p.fused_out[i] = unc1; p.fused_out[n + i] = cnd1; }
     }
-    const float e0 = unc0 + p.gs * (cnd0 - unc0);
-    const float e1 = unc1 + p.gs * (cnd1 - unc1);
-    const float l0 = cx * p.latents[i] + ce * e0;
-    const float l1 = cx * p.latents[n + i] + ce * e1;
+    // explicit, identical fma sequences for both samples: the base and the edited sample must stay
+    // bit-identical whenever their inputs are (stage 1)
+    const float e0 = __fmaf_rn(p.gs, __fsub_rn(cnd0, unc0), unc0);
+    const float e1 = __fmaf_rn(p.gs, __fsub_rn(cnd1, unc1), unc1);
+    const float l0 = __fmaf_rn(ce, e0, __fmul_rn(cx, p.latents[i]));
+    const float l1 = __fmaf_rn(ce, e1, __fmul_rn(cx, p.latents[n + i]));
     p.latents[i] = l0; p.latents[n + i] = l1;
     if (p.mi_next) {
-      const float a0 = l0 * cin, a1 = l1 * cin;
+      const float a0 = __fmul_rn(l0, cin), a1 = __fmul_rn(l1, cin);
       if (p.out_dtype == OMG_F16) {
         f16* o = (f16*)p.mi_next;
         o[i] = (f16)a0; o[n + i] = (f16)a1; o[2 * n + i] = (f16)a0; o[3 * n + i] = (f16)a1;
@@ -200,24 +188,29 @@ __global__ void scale_model_input_kernel(const float* latents, const float* cin,
 }  // namespace
 
 extern "C" int omg_conv_in(int dtype, const void* X, int x_is_f32, int B, int Cin, int H, int W, const void* Wt,
-                           const void* bias, int Cout, void* Y, void* stream) {
+                           const void* bias, int Cout, void* workspace, void* Y, void* stream) {
   OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_conv_in: dtype");
-  OMG_REQUIRE(X && Wt && Y && Cout % 8 == 0 && Cout / 8 <= 256 && Cin > 0, "omg_conv_in: args");
-  const size_t lds = (size_t)Cout * 9 * Cin * sizeof(float);
-  OMG_REQUIRE(lds <= 64 * 1024, "omg_conv_in: weights exceed 64 KiB of LDS");
+  OMG_REQUIRE(X && Wt && Y && workspace && Cout % 8 == 0 && Cin > 0 && 9 * Cin <= 64, "omg_conv_in: args (9*Cin <= 64)");
   const long npix = (long)B * H * W;
   if (npix == 0) return OMG_OK;
-  const int ppb = 256 / (Cout / 8);
-  long blocks = (npix + ppb - 1) / ppb; if (blocks > 4096) blocks = 4096;
+  const int KP = 64;
+  long blocks = (npix + 255) / 256; if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OMG_F16) {
-    if (x_is_f32) OMG_LAUNCH((conv_in_kernel<f16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
-    else OMG_LAUNCH((conv_in_kernel<f16, f16>), dim3(blocks), dim3(256), lds, s, (const f16*)X, B, Cin, H, W, (const f16*)Wt, (const f16*)bias, Cout, (char*)Y);
+    if (x_is_f32) OMG_LAUNCH((im2col_in_kernel<f16, float>), dim3(blocks), dim3(256), 0, s, (const float*)X, B, Cin, H, W, KP, (char*)workspace);
+    else OMG_LAUNCH((im2col_in_kernel<f16, f16>), dim3(blocks), dim3(256), 0, s, (const f16*)X, B, Cin, H, W, KP, (char*)workspace);
   } else {
-    if (x_is_f32) OMG_LAUNCH((conv_in_kernel<bf16, float>), dim3(blocks), dim3(256), lds, s, (const float*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
-    else OMG_LAUNCH((conv_in_kernel<bf16, bf16>), dim3(blocks), dim3(256), lds, s, (const bf16*)X, B, Cin, H, W, (const bf16*)Wt, (const bf16*)bias, Cout, (char*)Y);
+    if (x_is_f32) OMG_LAUNCH((im2col_in_kernel<bf16, float>), dim3(blocks), dim3(256), 0, s, (const float*)X, B, Cin, H, W, KP, (char*)workspace);
+    else OMG_LAUNCH((im2col_in_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, s, (const bf16*)X, B, Cin, H, W, KP, (char*)workspace);
   }
-  return omg_check_launch("conv_in");
+  int rc = omg_check_launch("im2col_in");
+  if (rc) return rc;
+  omg_gemm_args g{};
+  g.dtype = dtype; g.M = (int)npix; g.N = Cout; g.K = KP;
+  g.A = workspace; g.lda = KP; g.W = Wt; g.ldw = KP;
+  g.groups = 1; g.rows_per_group = (int)npix; g.bias = bias; g.act = OMG_ACT_NONE; g.out_scale = 1.0f;
+  g.C = Y; g.ldc = Cout;
+  return omg_gemm(&g, stream);
 }
 
 extern "C" int omg_conv_out(int dtype, const void* X, int B, int H, int W, int Cin, const void* Wt, const void* bias,

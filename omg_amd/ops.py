@@ -309,16 +309,18 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 def conv_in(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
-    """NCHW latents (fp32 or `dtype`) -> NHWC features in `dtype`; w: [Cout][3][3][Cin] in `dtype`."""
+    """NCHW latents (fp32 or `dtype`) -> NHWC features in `dtype`; w: [Cout][64] from pack_conv_in_weight."""
     _dev(x_nchw)
     assert x_nchw.is_contiguous()
     B, Cin, H, W = x_nchw.shape
     Cout = w.shape[0]
+    assert w.shape[1] == 64 and w.is_contiguous()
     y = torch.empty((B, H, W, Cout), dtype=dtype, device=x_nchw.device)
+    ws = torch.empty((B * H * W, 64), dtype=dtype, device=x_nchw.device)
     is_f32 = x_nchw.dtype == torch.float32
     assert is_f32 or x_nchw.dtype == dtype
     L.check(L.lib().omg_conv_in(_DT[dtype], x_nchw.data_ptr(), int(is_f32), B, Cin, H, W, w.data_ptr(), _p(bias), Cout,
-                                y.data_ptr(), _stream()), "omg_conv_in")
+                                ws.data_ptr(), y.data_ptr(), _stream()), "omg_conv_in")
     return y
 
 
@@ -423,6 +425,14 @@ def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     """diffusers conv weight [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin] (K = (tap, cin)); pure layout."""
     co, ci, kh, kw = w_oihw.shape
     return w_oihw.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+
+
+def pack_conv_in_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """conv_in weight [Cout, Cin, 3, 3] -> [Cout, 64]: (ky, kx, ci) order, zero padded (one GEMM K-slice)."""
+    co, ci, kh, kw = w_oihw.shape
+    out = torch.zeros((co, 64), dtype=w_oihw.dtype, device=w_oihw.device)
+    out[:, : kh * kw * ci] = w_oihw.permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+    return out
 
 
 def geglu_row_perm(n_total: int) -> torch.Tensor:

@@ -359,7 +359,7 @@ class UNet2DConditionModel(nn.Module):
     # ------------------------------------------------------------------ forward
     def _boundary_weights(self):
         if not self._boundary:
-            self._boundary["in"] = self.conv_in.weight.data.permute(0, 2, 3, 1).contiguous()
+            self._boundary["in"] = ops.pack_conv_in_weight(self.conv_in.weight.data)
             self._boundary["out"] = self.conv_out.weight.data.permute(0, 2, 3, 1).contiguous()
         return self._boundary
 

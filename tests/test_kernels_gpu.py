@@ -251,7 +251,7 @@ def test_conv_in_out(dev, dtype):
     x = torch.randn(B, 4, H, W, generator=torch.Generator().manual_seed(0))
     w = rnd(C0, 4, 3, 3, dtype=dtype, dev=dev, scale=1 / 6)
     b = rnd(C0, dtype=dtype, dev=dev)
-    wp = w.permute(0, 2, 3, 1).contiguous()
+    wp = ops.pack_conv_in_weight(w)
     y = ops.conv_in(x.to(dev), wp, b, dtype)
     ref = F.conv2d(x, w.float().cpu(), b.float().cpu(), padding=1).permute(0, 2, 3, 1)
     close(y, ref, dtype)
