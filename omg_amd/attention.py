@@ -28,7 +28,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
-from .modules import Dropout, Linear
+from .modules import Dropout, Linear, LoraState
 
 
 class Attention(nn.Module):
@@ -56,7 +56,9 @@ class Attention(nn.Module):
         self.processor = FusedAttnProcessor()
         self._qkv = None          # fused [3*inner, C] weight for self-attention
         self._kv = None           # fused [2*inner, Cx] weight for cross-attention
-        self._kv_cache = None     # (key, K/V^T projections) of a constant encoder_hidden_states
+        self._qkv_slots = None    # merged-LoRA mode: [1+slots, 3*inner, C]
+        self._kv_slots = None
+        self._kv_cache = {}       # key -> (K, V^T, ctx) projections of constant encoder_hidden_states
 
     # ---- diffusers API
     def set_processor(self, processor) -> None:
@@ -91,7 +93,8 @@ class Attention(nn.Module):
 
     # ---- fused projections
     def invalidate_packed(self):
-        self._qkv = self._kv = self._kv_cache = None
+        self._qkv = self._kv = self._qkv_slots = self._kv_slots = None
+        self._kv_cache = {}
 
     def qkv_weight(self) -> torch.Tensor:
         if self._qkv is None:
@@ -104,7 +107,22 @@ class Attention(nn.Module):
         return self._kv
 
     def _has_lora(self) -> bool:
-        return self.to_q.lora_state is not None and self.to_q.lora_down is not None
+        st = self.to_q.lora_state
+        return st is not None and not st.merged and self.to_q.lora_down is not None
+
+    def _merged(self) -> Optional[LoraState]:
+        st = self.to_q.lora_state
+        return st if (st is not None and st.merged and self.to_q.w_slots is not None) else None
+
+    def qkv_slots(self) -> torch.Tensor:
+        if self._qkv_slots is None:
+            self._qkv_slots = torch.cat([self.to_q.w_slots, self.to_k.w_slots, self.to_v.w_slots], dim=1).contiguous()
+        return self._qkv_slots
+
+    def kv_slots(self) -> torch.Tensor:
+        if self._kv_slots is None:
+            self._kv_slots = torch.cat([self.to_k.w_slots, self.to_v.w_slots], dim=1).contiguous()
+        return self._kv_slots
 
     def project_self(self, x: torch.Tensor):
         """x (B,N,C) -> q, k views of one fused buffer, and V^T."""
@@ -113,25 +131,38 @@ class Attention(nn.Module):
         if self._has_lora():
             q = self.to_q(x); k = self.to_k(x); v = self.to_v(x)
         else:
-            qkv = ops.gemm(x.reshape(B * N, C), self.qkv_weight()).view(B, N, 3 * inner)
+            st = self._merged()
+            if st is not None:
+                qkv = ops.gemm(x.reshape(B * N, C), self.qkv_slots(), groups=st.groups, w_group_adapter=st.group_adapter)
+            else:
+                qkv = ops.gemm(x.reshape(B * N, C), self.qkv_weight())
+            qkv = qkv.view(B, N, 3 * inner)
             q, k, v = qkv[:, :, :inner], qkv[:, :, inner:2 * inner], qkv[:, :, 2 * inner:]
         return q, k, ops.transpose_v(v, self.heads)
 
     def project_cross(self, ctx: torch.Tensor):
         """ctx (B,Nk,Cx) -> k view and V^T; cached while the same ctx tensor (and LoRA state) is passed."""
         st = self.to_k.lora_state
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), None if st is None else st.group_adapter.data_ptr())
-        if self._kv_cache is not None and self._kv_cache[0] == key:
-            return self._kv_cache[1], self._kv_cache[2]
+        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), None if st is None else (st.group_adapter.data_ptr(), st.merged))
+        hit = self._kv_cache.get(key)
+        if hit is not None:
+            return hit[0], hit[1]
         B, Nk, Cx = ctx.shape
         inner = self.inner_dim
         if self._has_lora():
             k = self.to_k(ctx); v = self.to_v(ctx)
         else:
-            kv = ops.gemm(ctx.reshape(B * Nk, Cx), self.kv_weight()).view(B, Nk, 2 * inner)
+            ms = self._merged()
+            if ms is not None:
+                kv = ops.gemm(ctx.reshape(B * Nk, Cx), self.kv_slots(), groups=ms.groups, w_group_adapter=ms.group_adapter)
+            else:
+                kv = ops.gemm(ctx.reshape(B * Nk, Cx), self.kv_weight())
+            kv = kv.view(B, Nk, 2 * inner)
             k, v = kv[:, :, :inner], kv[:, :, inner:]
         vt = ops.transpose_v(v, self.heads)
-        self._kv_cache = (key, k, vt, ctx)   # keep ctx alive so the pointer cannot be recycled
+        if len(self._kv_cache) >= 4:                      # main / concept / batched contexts of one call
+            self._kv_cache.pop(next(iter(self._kv_cache)))
+        self._kv_cache[key] = (k, vt, ctx)                # keep ctx alive so the pointer cannot be recycled
         return k, vt
 
 
@@ -147,7 +178,7 @@ class FusedAttnProcessor:
 
     supports_fused_residual = True
 
-    def _qk_src(self, attn, is_cross: bool, n_tokens: int, batch: int, device):
+    def _qk_src(self, attn, is_cross: bool, n_tokens: int, batch: int, device, main_batch=None):
         return None
 
     def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
@@ -163,7 +194,8 @@ class FusedAttnProcessor:
         else:
             q, k, vt = attn.project_self(x)
         bypass = cross_attention_kwargs.pop("omg_bypass_controller", False)
-        src = None if bypass else self._qk_src(attn, is_cross, N, B, x.device)
+        main_b = cross_attention_kwargs.pop("omg_main_batch", None)       # first `main_b` samples are the p2p batch
+        src = None if bypass else self._qk_src(attn, is_cross, N, B, x.device, main_b)
         o = ops.attention(q, k, vt, attn.heads, attn.scale, qk_src=src)
         out = attn.to_out[0](o, residual=residual)
         return out
@@ -180,10 +212,11 @@ class RegionControlNet_AttnProcessor(FusedAttnProcessor):
     def _fusable(self) -> bool:
         return self.controller is None or getattr(self.controller, "is_pure_replacement", False)
 
-    def _qk_src(self, attn, is_cross, n_tokens, batch, device):
+    def _qk_src(self, attn, is_cross, n_tokens, batch, device, main_batch=None):
         if self.controller is None:
             return None
-        return self.controller.fused_qk_src(is_cross, n_tokens, batch, self.place_in_unet, device=device)
+        return self.controller.fused_qk_src(is_cross, n_tokens, main_batch or batch, self.place_in_unet, device=device,
+                                            total_batch=batch)
 
     def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  scale: float = 1.0, residual: Optional[torch.Tensor] = None, **cross_attention_kwargs):

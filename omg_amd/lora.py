@@ -62,13 +62,22 @@ class LoraBank:
         self.adapters = {a.name: a for a in adapters}
         self.slots: List[Tuple[Tuple[str, float], ...]] = []
         self.scale = 1.0
+        self.mode = "merged"
 
     def slot_of(self, combo: Sequence[Tuple[str, float]]) -> int:
         return self.slots.index(tuple((n, float(w)) for n, w in combo))
 
-    def build(self, slots: Sequence[Sequence[Tuple[str, float]]], scale: float = 1.0) -> None:
+    def build(self, slots: Sequence[Sequence[Tuple[str, float]]], scale: float = 1.0, mode: str = "merged") -> None:
         """Materialise the slot stacks on every target Linear.  ``slots[s]`` = [(adapter name, weight), ...];
-        ``scale`` is ``cross_attention_kwargs['scale']`` (0.8 in OMG, lora_pipeline.py:596)."""
+        ``scale`` is ``cross_attention_kwargs['scale']`` (0.8 in OMG, lora_pipeline.py:596).
+
+        mode="segment": keep A/B un-merged (PEFT's arithmetic: base(x) + s*B(A(x)), second K-segment of omg_gemm).
+        mode="merged" : additionally build ``w_slots[1+S, out, in] = [W, W + s*B_1 A_1, ...]`` (fp32 merge, one
+        rounding) so that a batch mixing base and concept samples runs ONE GEMM per layer with a per-sample weight
+        slot and zero LoRA overhead — 4.4 GB of HBM per concept, which a 288 GB part has to spare."""
+        if mode not in ("merged", "segment"):
+            raise ValueError(mode)
+        self.mode = mode
         self.slots = [tuple((n, float(w)) for n, w in s) for s in slots]
         self.scale = scale
         dev, dt = self.unet.device, self.unet.dtype
@@ -97,13 +106,16 @@ class LoraBank:
                     r0 += ad.rank
             lin.lora_down = down.to(dt).contiguous()
             lin.lora_up = up.to(dt).contiguous()
+            if mode == "merged":
+                base = lin.weight.data.float()
+                lin.w_slots = torch.stack([base] + [base + up[s_] @ down[s_] for s_ in range(len(self.slots))]).to(dt).contiguous()
         for m in self.unet.modules():
-            if isinstance(m, GEGLU):
+            if m is not self.unet and hasattr(m, "invalidate_packed") and not isinstance(m, Linear):
                 m.invalidate_packed()
 
     def clear(self) -> None:
         for m in self.unet.modules():
             if isinstance(m, Linear):
-                m.lora_down = m.lora_up = None
-            if hasattr(m, "invalidate_packed") and m is not self.unet:
-                m.invalidate_packed() if isinstance(m, GEGLU) else None
+                m.lora_down = m.lora_up = m.w_slots = None
+            if m is not self.unet and hasattr(m, "invalidate_packed") and not isinstance(m, Linear):
+                m.invalidate_packed()

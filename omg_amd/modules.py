@@ -23,11 +23,12 @@ from . import ops
 class LoraState:
     """Per-forward LoRA selection: which adapter slot each sample of the batch uses (-1 = none)."""
 
-    __slots__ = ("group_adapter", "groups")
+    __slots__ = ("group_adapter", "groups", "merged")
 
-    def __init__(self, group_adapter: torch.Tensor, groups: int):
-        self.group_adapter = group_adapter   # int32 device tensor [groups]
-        self.groups = groups
+    def __init__(self, group_adapter: torch.Tensor, groups: int, merged: bool = False):
+        self.group_adapter = group_adapter   # int32 device tensor [groups]: LoRA slot (segment mode, -1 = none)
+        self.groups = groups                 #   or merged-weight slot (merged mode, 0 = base weights)
+        self.merged = merged
 
 
 class _Packed(nn.Module):
@@ -62,11 +63,13 @@ class Linear(_Packed):
         # LoRA bank (set by omg_amd.lora.LoraBank): [slots, r, in], [slots, out, r] (up already scaled)
         self.lora_down: Optional[torch.Tensor] = None
         self.lora_up: Optional[torch.Tensor] = None
+        # merged mode: [1 + slots, out, in] = base weight followed by W + scale*B_s A_s per slot
+        self.w_slots: Optional[torch.Tensor] = None
         self.lora_state: Optional[LoraState] = None   # set per forward by the UNet
 
     def _lora(self, x2: torch.Tensor) -> Optional[ops.LoraSpec]:
         st = self.lora_state
-        if st is None or self.lora_down is None:
+        if st is None or st.merged or self.lora_down is None:
             return None
         t = ops.gemm(x2, self.lora_down, groups=st.groups, w_group_adapter=st.group_adapter)
         return ops.LoraSpec(t, self.lora_up, st.group_adapter)
@@ -75,12 +78,16 @@ class Linear(_Packed):
                 group_bias: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
+        r2 = residual.reshape(-1, self.out_features) if residual is not None else None
+        st = self.lora_state
+        if st is not None and st.merged and self.w_slots is not None:
+            y = ops.gemm(x2, self.w_slots, bias=self.bias, residual=r2, act=act, groups=st.groups, w_group_adapter=st.group_adapter)
+            return y.view(*shp[:-1], y.shape[-1])
         lora = self._lora(x2)
         if lora is not None:
             groups = self.lora_state.groups
             if x2.shape[0] % groups != 0:
                 raise L.OmgHipError("LoRA groups do not divide the row count")
-        r2 = residual.reshape(-1, self.out_features) if residual is not None else None
         y = ops.gemm(x2, self.weight, bias=self.bias, residual=r2, act=act, group_bias=group_bias, groups=groups, lora=lora)
         return y.view(*shp[:-1], y.shape[-1])
 
@@ -99,6 +106,8 @@ class GEGLU(_Packed):
             self._packed["b"] = self.proj.bias.data[perm].contiguous()
             if self.proj.lora_up is not None:
                 self._packed["up"] = self.proj.lora_up[:, perm].contiguous()
+            if self.proj.w_slots is not None:
+                self._packed["w_slots"] = self.proj.w_slots[:, perm].contiguous()
         return self._packed
 
     def invalidate_packed(self):
@@ -111,7 +120,10 @@ class GEGLU(_Packed):
         lora = None
         groups = 1
         st = self.proj.lora_state
-        if st is not None and self.proj.lora_down is not None:
+        if st is not None and st.merged and "w_slots" in pk:
+            y = ops.gemm(x2, pk["w_slots"], bias=pk["b"], act=L.ACT_GEGLU, groups=st.groups, w_group_adapter=st.group_adapter)
+            return y.view(*shp[:-1], y.shape[-1])
+        if st is not None and not st.merged and self.proj.lora_down is not None:
             t = ops.gemm(x2, self.proj.lora_down, groups=st.groups, w_group_adapter=st.group_adapter)
             lora = ops.LoraSpec(t, pk["up"], st.group_adapter)
             groups = st.groups

@@ -50,20 +50,30 @@ class KernelProfiler:
         e.record(torch.cuda.current_stream())
         return e
 
-    def end(self, kind: str, flops: float, start) -> None:
+    def end(self, kind: str, flops: float, start, tag=None) -> None:
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
-        self.records.append((kind, flops, start, e))
+        self.records.append((kind, flops, start, e, tag))
 
     def summary(self):
         """kind -> dict(launches, ms, flops); call after torch.cuda.synchronize()."""
         out = {}
-        for kind, fl, s, e in self.records:
+        for kind, fl, s, e, _ in self.records:
             d = out.setdefault(kind, dict(launches=0, ms=0.0, flops=0.0))
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += fl
         return out
+
+    def by_tag(self):
+        """(kind, tag) -> dict(launches, ms, flops), sorted by total time."""
+        out = {}
+        for kind, fl, s, e, tag in self.records:
+            d = out.setdefault((kind, tag), dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+        return sorted(out.items(), key=lambda kv: -kv[1]["ms"])
 
 
 _PROF: Optional[KernelProfiler] = None
@@ -144,7 +154,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     if _PROF is not None:
         t0 = _PROF.begin()
         L.check(L.lib().omg_gemm(C.byref(args), _stream()), "omg_gemm")
-        _PROF.end("gemm", 2.0 * M * N * (K + args.K2), t0)
+        _PROF.end("gemm", 2.0 * M * N * (K + args.K2), t0, ("lin", M, N, K, args.K2, groups if adapter is not None else 1, act))
         return out
     L.check(L.lib().omg_gemm(C.byref(args), _stream()), "omg_gemm")
     return out
@@ -185,7 +195,7 @@ def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, up
     if _PROF is not None:
         t0 = _PROF.begin()
         L.check(L.lib().omg_conv2d(C.byref(a), _stream()), "omg_conv2d")
-        _PROF.end("gemm", 2.0 * B * Hout * Wout * Cout * ksize * ksize * (C1 + C2), t0)
+        _PROF.end("gemm", 2.0 * B * Hout * Wout * Cout * ksize * ksize * (C1 + C2), t0, ("conv", B * Hout * Wout, Cout, ksize * ksize * (C1 + C2), 0, 1, 0))
         return y
     L.check(L.lib().omg_conv2d(C.byref(a), _stream()), "omg_conv2d")
     return y
@@ -237,7 +247,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, sc
     if _PROF is not None:
         t0 = _PROF.begin()
         L.check(L.lib().omg_attn_fwd(C.byref(a), _stream()), "omg_attn_fwd")
-        _PROF.end("attn", 4.0 * B * heads * Nq * k.shape[1] * 64, t0)
+        _PROF.end("attn", 4.0 * B * heads * Nq * k.shape[1] * 64, t0, ("attn", B, heads, Nq, k.shape[1]))
         return out
     L.check(L.lib().omg_attn_fwd(C.byref(a), _stream()), "omg_attn_fwd")
     return out

@@ -80,13 +80,15 @@ class ConceptModels:
             adapter_weights = [1.0] * len(adapter_names)
         self._active = tuple((n, float(w)) for n, w in zip(adapter_names, adapter_weights))
 
-    def lora_state(self, slots: Sequence[int]) -> Optional[LoraState]:
+    def lora_state(self, slots: Sequence[int], merged: bool = False) -> Optional[LoraState]:
+        """``slots[b]`` = LoRA slot of sample b.  segment mode: -1 = no adapter; merged mode: 0 = base weights,
+        s+1 = bank slot s."""
         if self.bank is None:
             return None
-        key = tuple(slots)
+        key = (tuple(slots), merged)
         st = self._state_cache.get(key)
         if st is None:
-            st = LoraState(torch.tensor(list(slots), dtype=torch.int32, device=self._unet.device), len(slots))
+            st = LoraState(torch.tensor(list(slots), dtype=torch.int32, device=self._unet.device), len(slots), merged)
             self._state_cache[key] = st
         return st
 
@@ -94,7 +96,10 @@ class ConceptModels:
         """Concept forward where sample b uses LoRA slot ``slots[b]``; bypasses the p2p controller."""
         cak = dict(kw.pop("cross_attention_kwargs", None) or {})
         cak["omg_bypass_controller"] = True
-        self._unet.set_lora_state(self.lora_state(slots))
+        merged = self.bank is not None and self.bank.mode == "merged"
+        if merged:
+            slots = [s + 1 for s in slots]            # slot 0 of the merged stacks is the base weight
+        self._unet.set_lora_state(self.lora_state(slots, merged))
         try:
             return self._unet(sample, timestep, encoder_hidden_states=encoder_hidden_states, cross_attention_kwargs=cak, **kw)
         finally:
@@ -156,7 +161,8 @@ class LoraMultiConceptPipeline:
                  controller=None, concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None,
                  region_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, lora_list: Optional[Sequence[str]] = None,
                  styleL: Optional[bool] = None, region_prompt_embeds: Optional[Sequence[Tuple[torch.Tensor, ...]]] = None,
-                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, **kwargs):
+                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START,
+                 lora_mode: str = "merged", **kwargs):
         if image is not None:
             raise L.OmgHipError("ControlNet conditioning (image=) is a 'next' row of SURVEY §8f (N2) and is not implemented")
         if eta != 0.0:
@@ -215,8 +221,9 @@ class LoraMultiConceptPipeline:
             scale = (cross_attention_kwargs or {}).get("scale", 1.0)
             combos = [((lora_list[c], 0.7), ("style", 0.5)) if styleL else ((lora_list[c], 1.0),) for c in active]
             if concept_models.bank is not None:
-                if [tuple(c) for c in combos] != list(concept_models.bank.slots) or concept_models.bank.scale != scale:
-                    concept_models.bank.build(combos, scale=scale)
+                bank = concept_models.bank
+                if [tuple(c) for c in combos] != list(bank.slots) or bank.scale != scale or bank.mode != lora_mode:
+                    bank.build(combos, scale=scale, mode=lora_mode)
                 slots = [s for s in range(len(active)) for _ in range(2)]
             else:
                 slots = [-1] * (2 * len(active))
@@ -225,26 +232,44 @@ class LoraMultiConceptPipeline:
             c_text = torch.cat([torch.cat([region_prompt_embeds[c][2], region_prompt_embeds[c][3]], dim=0) for c in active], dim=0)
             c_tids = self._add_time_ids(original_size, crops_coords_top_left, target_size, 2 * len(active), dev)
             emb_conc = self._all_step_embeddings(ts, c_text.to(device=dev, dtype=dt), c_tids)   # (S, 2Ka, D)
-        # ---- persistent step buffers
+        # ---- persistent step buffers.  One input buffer / one output buffer for [main batch | concept batch]:
+        # in merged-LoRA mode a fused step is ONE UNet forward over all 4 + 2*Ka samples.
         coef = self.scheduler.coef_table(dev)
         step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
-        model_input = torch.empty((4, lat.shape[1], Hl, Wl), dtype=dt, device=dev)
-        ops.scale_model_input(lat, self.scheduler.cin0(dev), model_input)
-        noise = torch.empty((4, lat.shape[1], Hl, Wl), dtype=torch.float32, device=dev)
         Ka = len(active)
-        region_noise = torch.empty((max(Ka, 1) * 2, lat.shape[1], Hl, Wl), dtype=torch.float32, device=dev)
-        region_in = torch.empty((max(Ka, 1) * 2, lat.shape[1], Hl, Wl), dtype=dt, device=dev)
+        nb = 4 + 2 * Ka
+        Cl = lat.shape[1]
+        xin = torch.empty((nb, Cl, Hl, Wl), dtype=dt, device=dev)
+        nout = torch.empty((nb, Cl, Hl, Wl), dtype=torch.float32, device=dev)
+        model_input, region_in = xin[:4], xin[4:]
+        noise, region_noise = nout[:4], nout[4:]
+        ops.scale_model_input(lat, self.scheduler.cin0(dev), model_input)
         region_list: List[Optional[torch.Tensor]] = [None] * K
         for j, c in enumerate(active):
             region_list[c] = region_noise[2 * j: 2 * j + 2]
         main_kw = dict(cross_attention_kwargs or {})
         main_kw.pop("scale", None)
+        batched = fuse_possible and concept_models.bank is not None and concept_models.bank.mode == "merged"
+        if batched:
+            ehs_all = torch.cat([ehs, c_ehs], dim=0).contiguous()
+            emb_all = torch.cat([emb_main, emb_conc], dim=1).contiguous()             # (S, nb, D)
+            state_all = concept_models.lora_state([0, 0, 0, 0] + [s + 1 for s in slots], merged=True)
+            all_kw = dict(main_kw)
+            all_kw["omg_main_batch"] = 4
 
         def one_step(i: int, fused: bool):
-            self.unet(model_input, None, encoder_hidden_states=ehs, cross_attention_kwargs=main_kw, emb=emb_main[i], out=noise)
-            if fused:
+            if fused and batched:
                 region_in.copy_(model_input[3:4].expand(2 * Ka, -1, -1, -1))      # latent_model_input[3:4] duplicated (:583-585)
-                concept_models.unet_batched(region_in, None, c_ehs, slots, emb=emb_conc[i], out=region_noise)
+                self.unet.set_lora_state(state_all)
+                try:
+                    self.unet(xin, None, encoder_hidden_states=ehs_all, cross_attention_kwargs=all_kw, emb=emb_all[i], out=nout)
+                finally:
+                    self.unet.set_lora_state(None)
+            else:
+                self.unet(model_input, None, encoder_hidden_states=ehs, cross_attention_kwargs=main_kw, emb=emb_main[i], out=noise)
+                if fused:
+                    region_in.copy_(model_input[3:4].expand(2 * Ka, -1, -1, -1))
+                    concept_models.unet_batched(region_in, None, c_ehs, slots, emb=emb_conc[i], out=region_noise)
             ops.fuse_cfg_step(noise, lat, coef, step_idx, guidance_scale=guidance_scale, fuse=fused,
                               region_preds=region_list if fused else [None] * K, masks=masks if fused else [None] * K,
                               model_input_next=model_input, advance=True)

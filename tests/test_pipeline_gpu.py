@@ -34,8 +34,8 @@ def embeds(cfg, n, seed, dtype):
     return e, p
 
 
-@pytest.mark.parametrize("sched", ["ddim", "euler"])
-def test_two_stage_loop_matches_oracle(dev, sched):
+@pytest.mark.parametrize("sched,lora_mode", [("ddim", "merged"), ("euler", "merged"), ("ddim", "segment")])
+def test_two_stage_loop_matches_oracle(dev, sched, lora_mode):
     dtype = torch.float16
     cfg, ocfg, sd, unet = setup(dev, dtype)
     L = cfg.sample_size
@@ -90,10 +90,10 @@ def test_two_stage_loop_matches_oracle(dev, sched):
                    height=H, width=W, num_inference_steps=S, guidance_scale=gs, latents=lat0,
                    cross_attention_kwargs={"scale": 0.8}, controller=pctl, concept_models=concept, stage=stage,
                    region_masks=masks, lora_list=["c0", "c1", "c2"], styleL=False, region_prompt_embeds=regions,
-                   trajectory=traj, fusion_start=fstart).images
+                   trajectory=traj, fusion_start=fstart, lora_mode=lora_mode).images
         ref, rec = oracle_run(stage)
         errs = [(a.float().cpu() - b).abs().max().item() for a, b in zip(traj, rec)]
-        print(f"{sched} stage {stage}: per-step max|d| = " + " ".join(f"{e:.2e}" for e in errs), " latent rms", ref.pow(2).mean().sqrt().item())
+        print(f"{sched}/{lora_mode} stage {stage}: per-step max|d| = " + " ".join(f"{e:.2e}" for e in errs), " latent rms", ref.pow(2).mean().sqrt().item())
         # fp16 noise-prediction error (~4e-3) is amplified by CFG (x16 at gs 7.5) and the scheduler's eps
         # coefficient every step; a logic error (mask, ordering, coefficient) would be O(latent rms)
         rel = errs[-1] / ref.pow(2).mean().sqrt().item()
