@@ -48,6 +48,7 @@ struct GemmP {
   int Hin, Win, C1, C2, Hout, Wout, ksize, stride, upsample;
   const char* X2;
   int tiles_m, tiles_n;              // tiles_m is per group
+  int dbg;                           // ablation bits (tools only): 1 = no DMA in loop, 2 = no wait/barrier, 4 = no ds_read
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -324,10 +325,103 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 // LDS image per stage: rows of 64 B (4 chunks of 16 B), chunk ^= (row >> 2) & 3 (16 lanes of a
 // ds_read_b128 group -> 16 distinct slots); applied on the DMA source side and on the read (rule 21).
 constexpr int BK3 = 32;
-constexpr int NST3 = 4;
 
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
-__global__ __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_) / 4) void gemm_kernel_v3(GemmP p) {
+template <int N> OMG_DEV void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Row-coalesced epilogue shared by the large-tile kernels: one 32-row slab of every wave per pass through a
+// [32][STAGE_LD] fp32 staging area in LDS (bias / per-sample bias / SiLU / GEGLU / residual applied on 16-byte rows).
+template <typename T, int MT>
+OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, int w, int lane, int m0, int n0, int wm, int wn,
+                            int m_end) {
+  constexpr int NT = 2;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int wm0 = m0 + wm * (MT * 32);
+  const int wn0 = n0 + wn * 64;
+  float* stage = (float*)smem + w * (32 * STAGE_LD);
+  const int sub = lane & 7, rsub = lane >> 3;
+  const int gc = wn0 + sub * 8;
+  float bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+  const bool geglu = p.act == OMG_ACT_GEGLU;
+  if (!geglu && p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
+      }
+    __syncthreads();
+    if (geglu) {
+      const int s4 = lane & 3, r4 = lane >> 2;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + r4;
+        const int gm = wm0 + i * 32 + row;
+        const int gcc = wn0 + s4 * 8;
+        if (gm < m_end && gcc < p.N) {
+          float v[8], g[8];
+          const float* sp = stage + row * STAGE_LD + s4 * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
+          if (p.bias) {
+            float b1[8], b2[8];
+            unpack8<T>(*(const u32x4*)(p.bias + (long)gcc * 2), b1);
+            unpack8<T>(*(const u32x4*)(p.bias + (long)(gcc + 32) * 2), b2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[e] += b1[e]; g[e] += b2[e]; }
+          }
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
+          *(u32x4*)(p.C + ((long)gm * p.ldc + (wn0 >> 1) + s4 * 8) * 2) = pack8<T>(o);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rsub;
+        const int gm = wm0 + i * 32 + row;
+        if (gm < m_end && gc < p.N) {
+          float v[8];
+          const float* sp = stage + row * STAGE_LD + sub * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
+          if (p.group_bias) {
+            float gb[8];
+            const int g = gm / p.rows_per_group;
+            unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += gb[e];
+          }
+          if (p.act == OMG_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+          if (p.residual) {
+            float rv[8];
+            unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          }
+          *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST3>
+__global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
   constexpr int NW = WM_ * WN_;
   constexpr int MT = BM_ / WM_ / 32;             // 32-row MFMA tiles per wave (2 or 4)
   constexpr int NT = BN_ / WN_ / 32;             // must be 2
@@ -415,7 +509,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_) / 4) void gemm_kernel_v
   const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
 
   auto issue = [&](int kt) {
-    char* sbase = smem + (kt & (NST3 - 1)) * STAGE_BYTES;
+    char* sbase = smem + (kt % NST3) * STAGE_BYTES;
     const bool s2 = kt >= nk1;
     const int k0 = (s2 ? kt - nk1 : kt) * BK3;
     const int Kseg = s2 ? p.K2 : p.K;
@@ -490,119 +584,63 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, (WM_ * WN_) / 4) void gemm_kernel_v
   for (int s = 0; s < NST3 - 1; ++s)
     if (s < nk) issue(s);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = nk - 1 - kt;         // stages still in flight behind stage kt (max 2)
-    if (ahead >= 2) {
-      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (ahead == 1) {
-      if constexpr (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  // Software-pipelined main loop: the ONE barrier per stage sits between the two k-steps, and every
+  // ds_read_b128 batch is issued one k-step ahead of the MFMAs that consume it (two fragment sets in
+  // registers), so LDS latency and the DMA issue are always covered by this wave's own MFMAs.
+  //   [F0 = frags(kt, ks0) ready]  read F1 = (kt, ks1) | MFMA F0 | wait stage kt+1, barrier, DMA stage kt+NST-1
+  //                                read F0 = (kt+1, ks0) | MFMA F1
+  V8 af0[MT], bf0[NT], af1[MT], bf1[NT];
+  {
+    const int inflight = (nk - 1) < (NST3 - 2) ? (nk - 1) : (NST3 - 2);
+    if (inflight >= 2) wait_vmcnt<2 * NDMA>();
+    else if (inflight == 1) wait_vmcnt<NDMA>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (kt + NST3 - 1 < nk) issue(kt + NST3 - 1);
-    const char* sb = smem + (kt & (NST3 - 1)) * STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      V8 af[MT], bf[NT];
+    for (int j = 0; j < NT; ++j) bf0[j] = *(const V8*)(smem + bro[j][0]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *(const V8*)(sb + bro[j][ks]);
+    for (int i = 0; i < MT; ++i) af0[i] = *(const V8*)(smem + aro[i][0]);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + (kt % NST3) * STAGE_BYTES;
+    if (!(p.dbg & 4)) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + aro[i][ks]);
+      for (int j = 0; j < NT; ++j) bf1[j] = *(const V8*)(sb + bro[j][1]);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[i], bf[j], acc[i][j]);
+      for (int i = 0; i < MT; ++i) af1[i] = *(const V8*)(sb + aro[i][1]);
     }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af0[i], bf0[j], acc[i][j]);
+    if (kt + 1 < nk) {
+      // stage kt+1 must have landed; stages up to kt+NST-2 have been issued
+      const int later = nk - 2 - kt;                       // stages beyond kt+1 that exist
+      if (!(p.dbg & 2)) {
+        if (NST3 >= 4 && later >= 1) wait_vmcnt<NDMA>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+      if (kt + NST3 - 1 < nk && !(p.dbg & 1)) issue(kt + NST3 - 1);
+      const char* sn = smem + ((kt + 1) % NST3) * STAGE_BYTES;
+      if (!(p.dbg & 4)) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf0[j] = *(const V8*)(sn + bro[j][0]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af0[i] = *(const V8*)(sn + aro[i][0]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af1[i], bf1[j], acc[i][j]);
   }
 
-  // ---- epilogue: one 32-row slab of every wave per pass through a [32][STAGE_LD] fp32 staging area
-  const int wm0 = m0 + wm * (MT * 32);
-  const int wn0 = n0 + wn * 64;
-  float* stage = (float*)smem + w * (32 * STAGE_LD);
-  const int sub = lane & 7, rsub = lane >> 3;
-  const int gc = wn0 + sub * 8;
-  float bv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-  const bool geglu = p.act == OMG_ACT_GEGLU;
-  if (!geglu && p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
-      }
-    __syncthreads();
-    if (geglu) {
-      const int s4 = lane & 3, r4 = lane >> 2;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 16 + r4;
-        const int gm = wm0 + i * 32 + row;
-        const int gcc = wn0 + s4 * 8;
-        if (gm < m_end && gcc < p.N) {
-          float v[8], g[8];
-          const float* sp = stage + row * STAGE_LD + s4 * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
-          if (p.bias) {
-            float b1[8], b2[8];
-            unpack8<T>(*(const u32x4*)(p.bias + (long)gcc * 2), b1);
-            unpack8<T>(*(const u32x4*)(p.bias + (long)(gcc + 32) * 2), b2);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] += b1[e]; g[e] += b2[e]; }
-          }
-          float o[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
-          *(u32x4*)(p.C + ((long)gm * p.ldc + (wn0 >> 1) + s4 * 8) * 2) = pack8<T>(o);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + rsub;
-        const int gm = wm0 + i * 32 + row;
-        if (gm < m_end && gc < p.N) {
-          float v[8];
-          const float* sp = stage + row * STAGE_LD + sub * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
-          if (p.group_bias) {
-            float gb[8];
-            const int g = gm / p.rows_per_group;
-            unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += gb[e];
-          }
-          if (p.act == OMG_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-          if (p.residual) {
-            float rv[8];
-            unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
-          }
-          *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
-        }
-      }
-    }
-  }
+  epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
 
-constexpr int lds_bytes_v3(int bm, int bn, int nw) {
-  const int ring = NST3 * (bm + bn) * BK3 * 2;
+constexpr int lds_bytes_v3(int bm, int bn, int nw, int nst) {
+  const int ring = nst * (bm + bn) * BK3 * 2;
   const int epi = nw * 32 * STAGE_LD * 4;
   return ring > epi ? ring : epi;
 }
@@ -610,21 +648,23 @@ constexpr int lds_bytes_v3(int bm, int bn, int nw) {
 
 
 bool g_use_glds = true;
+int g_dbg = 0;
 int g_variant = 0;   // 0 = heuristic, 1 = 128x128 v1, 3 = 256x256, 4 = 256x128
 
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST_>
 int launch_v3(GemmP p, hipStream_t s, int mrows) {
-  constexpr int lds = lds_bytes_v3(BM_, BN_, WM_ * WN_);
+  constexpr int lds = lds_bytes_v3(BM_, BN_, WM_ * WN_, NST_);
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + BM_ - 1) / BM_;
   p.tiles_n = (p.N + BN_ - 1) / BN_;
+  p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
   return omg_check_launch("gemm_v3");
 }
 
@@ -648,9 +688,11 @@ template <typename T, bool CONV>
 int launch(const GemmP& p, hipStream_t s) {
   const int mrows = p.tile_groups > 1 ? p.rows_per_group : p.M;
   if (g_use_glds) {
-    const int v = choose_variant(mrows, p.tile_groups, p.N);
-    if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4>(p, s, mrows);
-    if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2>(p, s, mrows);
+    int v = choose_variant(mrows, p.tile_groups, p.N);
+    if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4, 4>(p, s, mrows);
+    if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2, 4>(p, s, mrows);
+    if (v == 5) return launch_v3<T, CONV, 256, 128, 2, 2, 3>(p, s, mrows);   // 4 waves x (128x64), 72 KiB: 2 blocks/CU
+    if (v == 6) return launch_v3<T, CONV, 128, 256, 1, 4, 3>(p, s, mrows);
   }
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
@@ -680,7 +722,7 @@ void ensure_attrs() {
 }  // namespace
 
 extern "C" void omg_debug_set_glds(int on) { g_use_glds = on != 0; }
-extern "C" void omg_debug_set_gemm_variant(int v) { g_variant = v; }
+extern "C" void omg_debug_set_gemm_variant(int v) { g_variant = v & 0xff; g_dbg = v >> 8; }
 
 extern "C" int omg_gemm(const omg_gemm_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_gemm: null args");
