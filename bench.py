@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-latent", type=int, default=64, choices=[64, 128])
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (NOT a valid benchmark)")
+    ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
 
     from omg_amd import controller as pc, ops, parallel
@@ -106,7 +107,8 @@ def main():
         ctl.reset()                                                                   # inference_lora.py:274
         return pipe(height=HW, width=HW, num_inference_steps=args.denoise_steps, guidance_scale=7.5,
                     cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
-                    region_masks=masks, lora_list=["concept0", "concept1"], styleL=False, output_type="latent", **inp, **kw).images
+                    region_masks=masks, lora_list=["concept0", "concept1"], styleL=False, output_type="latent",
+                    use_graph=not args.no_graph, **inp, **kw).images
 
     for i in range(args.warmup):
         lat = run_image(inputs[i])
@@ -131,7 +133,9 @@ def main():
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),
                       "global_batch": world, "main_batch": 4, "concept_batch": 4, "accounting": "stage-2 only, as executed by the reference "
                       "(200 main + 136 concept sample-forwards = 2.273 PFLOP/image); no redundancy shortcuts",
-                      "parallelism": f"dp{world}", "tiny_debug": bool(args.tiny)},
+                      "parallelism": f"dp{world}", "tiny_debug": bool(args.tiny),
+                      "step_loop": "eager" if args.no_graph else "hipGraph replay (3 captured step regimes)", "lora": "merged weight slots, "
+                      "main + concept samples batched (B=8) per fused step"},
            "end_to_end_tflops_per_gpu": (N_MAIN + N_CONCEPT) * SAMPLE_FWD_TFLOP * value / world if not args.tiny else None}
 
     if rank == 0 and not args.no_roofline:

@@ -230,6 +230,10 @@ typedef struct {
 
 int omg_fuse_cfg_step(const omg_step_args* a, void* stream);
 
+/* out[0:n] = table[*step_idx * n : (*step_idx + 1) * n]: per-step conditioning (time/text embedding rows, hoisted out
+ * of the loop by the host) selected with the DEVICE step counter, so a captured step graph has no host argument. */
+int omg_gather_step(int dtype, const void* table, const int32_t* step_idx, void* out, int64_t n_per_step, void* stream);
+
 /* model_input[4,C,H,W] (dtype) = cin * cat([latents]*2)  — first iteration of the loop */
 int omg_scale_model_input(int dtype, const float* latents, const float* coef_cin, int n_per_sample, void* out, void* stream);
 

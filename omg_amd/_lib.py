@@ -84,6 +84,7 @@ SYMBOLS = {
     "omg_copy2d": (c_i32, [c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "omg_fuse_cfg_step": (c_i32, [C.POINTER(StepArgs), c_vp]),
     "omg_scale_model_input": (c_i32, [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "omg_gather_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "omg_attn_probs": (c_i32, [C.POINTER(AttnArgs), c_vp, c_vp]),
     "omg_attn_apply_probs": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "omg_debug_set_glds": (None, [c_i32]),

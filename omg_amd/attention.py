@@ -141,28 +141,37 @@ class Attention(nn.Module):
         return q, k, ops.transpose_v(v, self.heads)
 
     def project_cross(self, ctx: torch.Tensor):
-        """ctx (B,Nk,Cx) -> k view and V^T; cached while the same ctx tensor (and LoRA state) is passed."""
+        """ctx (B,Nk,Cx) -> K view and V^T of a constant ``encoder_hidden_states``.
+
+        Cached per (ctx shape, LoRA state): a hit returns the stored projections; a miss for a shape seen before
+        recomputes INTO the stored tensors (pointers stay valid for captured hipGraphs); entries keep ``ctx`` alive."""
         st = self.to_k.lora_state
-        key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape), None if st is None else (st.group_adapter.data_ptr(), st.merged))
-        hit = self._kv_cache.get(key)
-        if hit is not None:
-            return hit[0], hit[1]
+        skey = (tuple(ctx.shape), None if st is None else (st.group_adapter.data_ptr(), st.merged))
+        stamp = (ctx.data_ptr(), ctx._version)
+        hit = self._kv_cache.get(skey)
+        if hit is not None and hit[0] == stamp:
+            return hit[1], hit[2]
         B, Nk, Cx = ctx.shape
         inner = self.inner_dim
+        kv_out = hit[4] if hit is not None else None
+        vt_out = hit[2] if hit is not None else None
         if self._has_lora():
             k = self.to_k(ctx); v = self.to_v(ctx)
+            kv_out = None
         else:
             ms = self._merged()
+            x2 = ctx.reshape(B * Nk, Cx)
             if ms is not None:
-                kv = ops.gemm(ctx.reshape(B * Nk, Cx), self.kv_slots(), groups=ms.groups, w_group_adapter=ms.group_adapter)
+                kv = ops.gemm(x2, self.kv_slots(), groups=ms.groups, w_group_adapter=ms.group_adapter, out=kv_out)
             else:
-                kv = ops.gemm(ctx.reshape(B * Nk, Cx), self.kv_weight())
+                kv = ops.gemm(x2, self.kv_weight(), out=kv_out)
+            kv_out = kv
             kv = kv.view(B, Nk, 2 * inner)
             k, v = kv[:, :, :inner], kv[:, :, inner:]
-        vt = ops.transpose_v(v, self.heads)
-        if len(self._kv_cache) >= 4:                      # main / concept / batched contexts of one call
+        vt = ops.transpose_v(v, self.heads, out=vt_out)
+        if hit is None and len(self._kv_cache) >= 4:
             self._kv_cache.pop(next(iter(self._kv_cache)))
-        self._kv_cache[key] = (k, vt, ctx)                # keep ctx alive so the pointer cannot be recycled
+        self._kv_cache[skey] = (stamp, k, vt, ctx, kv_out)
         return k, vt
 
 

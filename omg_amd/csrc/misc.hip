@@ -110,6 +110,13 @@ __global__ void copy2d_kernel(const T* src, long lds_, T* dst, long ldd, long ro
   }
 }
 
+// out[0:n] = table[(*step_idx) * n : ...]  (2-byte elements): selects the per-step conditioning row block on the
+// device so that a captured step graph needs no host-side argument (hipGraph replay freezes kernel arguments).
+__global__ void gather_step_kernel(const uint16_t* table, const int* step_idx, uint16_t* out, long n) {
+  const long base = (long)(*step_idx) * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = table[base + i];
+}
+
 // ------------------------------------------------------ fused step kernel
 struct StepP {
   int C, H, W, Hm, Wm, n_concepts, fuse;
@@ -257,6 +264,14 @@ extern "C" int omg_copy2d(int dtype, const void* src, int64_t lds_, void* dst, i
   // f16 and bf16 are both 2-byte copies
   OMG_LAUNCH(copy2d_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)src, (long)lds_, (uint16_t*)dst, (long)ldd, (long)rows, (long)cols);
   return omg_check_launch("copy2d");
+}
+
+extern "C" int omg_gather_step(int dtype, const void* table, const int32_t* step_idx, void* out, int64_t n_per_step, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_gather_step: dtype");
+  OMG_REQUIRE(table && step_idx && out && n_per_step > 0, "omg_gather_step: args");
+  long blocks = (n_per_step + 255) / 256; if (blocks > 1024) blocks = 1024;
+  OMG_LAUNCH(gather_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)table, (const int*)step_idx, (uint16_t*)out, (long)n_per_step);
+  return omg_check_launch("gather_step");
 }
 
 extern "C" int omg_fuse_cfg_step(const omg_step_args* a, void* stream) {

@@ -201,13 +201,14 @@ def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, up
     return y
 
 
-def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None) -> torch.Tensor:
+def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``v``: (B, Nkv, >=heads*64) view with unit inner stride -> Vt (B, heads, 64, Nkv_pad)."""
     _dev(v)
     B, Nkv = v.shape[0], v.shape[1]
     if nkv_pad is None:
         nkv_pad = (Nkv + 63) // 64 * 64
-    vt = torch.empty((B, heads, 64, nkv_pad), dtype=v.dtype, device=v.device)
+    vt = out if out is not None else torch.empty((B, heads, 64, nkv_pad), dtype=v.dtype, device=v.device)
+    assert vt.is_contiguous() and tuple(vt.shape) == (B, heads, 64, nkv_pad)
     L.check(L.lib().omg_transpose_v(_dt(v), v.data_ptr(), v.stride(1), v.stride(0), B, heads, Nkv, nkv_pad,
                                     vt.data_ptr(), _stream()), "omg_transpose_v")
     return vt
@@ -418,6 +419,14 @@ def fuse_cfg_step(noise_pred: torch.Tensor, latents: torch.Tensor, coef: torch.T
         assert fused_noise_out.dtype == torch.float32 and fused_noise_out.is_contiguous()
         a.fused_noise_out = fused_noise_out.data_ptr()
     L.check(L.lib().omg_fuse_cfg_step(C.byref(a), _stream()), "omg_fuse_cfg_step")
+
+
+def gather_step(table: torch.Tensor, step_idx: torch.Tensor, out: torch.Tensor) -> None:
+    """out = table[step_idx] with the step index read ON THE DEVICE (table: (S, ...), out: (...))."""
+    _dev(table)
+    assert table.is_contiguous() and out.is_contiguous() and table.shape[1:] == out.shape and step_idx.dtype == torch.int32
+    L.check(L.lib().omg_gather_step(_dt(table), table.data_ptr(), step_idx.data_ptr(), out.data_ptr(), out.numel(), _stream()),
+            "omg_gather_step")
 
 
 def scale_model_input(latents: torch.Tensor, coef_cin: torch.Tensor, out: torch.Tensor) -> None:

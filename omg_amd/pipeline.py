@@ -125,7 +125,7 @@ class LoraMultiConceptPipeline:
         self.encode_prompt = encode_prompt
         self.vae_decode = vae_decode
         self.vae_scale_factor = 8
-        self._graphs: Dict[Tuple, object] = {}
+        self._engines: Dict[Tuple, SimpleNamespace] = {}
 
     @property
     def _execution_device(self):
@@ -232,15 +232,49 @@ class LoraMultiConceptPipeline:
             c_text = torch.cat([torch.cat([region_prompt_embeds[c][2], region_prompt_embeds[c][3]], dim=0) for c in active], dim=0)
             c_tids = self._add_time_ids(original_size, crops_coords_top_left, target_size, 2 * len(active), dev)
             emb_conc = self._all_step_embeddings(ts, c_text.to(device=dev, dtype=dt), c_tids)   # (S, 2Ka, D)
-        # ---- persistent step buffers.  One input buffer / one output buffer for [main batch | concept batch]:
-        # in merged-LoRA mode a fused step is ONE UNet forward over all 4 + 2*Ka samples.
-        coef = self.scheduler.coef_table(dev)
-        step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+        # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
         Ka = len(active)
         nb = 4 + 2 * Ka
         Cl = lat.shape[1]
-        xin = torch.empty((nb, Cl, Hl, Wl), dtype=dt, device=dev)
-        nout = torch.empty((nb, Cl, Hl, Wl), dtype=torch.float32, device=dev)
+        batched = fuse_possible and concept_models.bank is not None and concept_models.bank.mode == "merged"
+        if use_graph and fuse_possible and not batched:
+            raise L.OmgHipError("use_graph needs lora_mode='merged' (segment-mode K/V projections are not pointer-stable)")
+        mshape = tuple(masks[active[0]].shape) if active else (0, 0)
+        D = emb_main.shape[-1]
+        key = (S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
+               str(dt), batched, bool(styleL), tuple(lora_list), mshape, tuple(ehs.shape), id(controller))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = SimpleNamespace(graphs={}, warmed=set(), pool=None)
+            eng.lat = torch.empty((2, Cl, Hl, Wl), dtype=torch.float32, device=dev)
+            eng.xin = torch.empty((nb, Cl, Hl, Wl), dtype=dt, device=dev)
+            eng.nout = torch.empty((nb, Cl, Hl, Wl), dtype=torch.float32, device=dev)
+            eng.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+            eng.ehs = torch.empty_like(ehs)
+            eng.emb_main = torch.empty((S, 4, D), dtype=dt, device=dev)
+            eng.emb_cur_main = torch.empty((4, D), dtype=dt, device=dev)
+            eng.masks = [torch.empty(mshape, dtype=torch.float32, device=dev) if c in active else None for c in range(K)]
+            if fuse_possible:
+                eng.c_ehs = torch.empty_like(c_ehs)
+                eng.emb_conc = torch.empty((S, 2 * Ka, D), dtype=dt, device=dev)
+                eng.emb_cur_conc = torch.empty((2 * Ka, D), dtype=dt, device=dev)
+            if batched:
+                eng.ehs_all = torch.empty((nb,) + tuple(ehs.shape[1:]), dtype=dt, device=dev)
+                eng.emb_all = torch.empty((S, nb, D), dtype=dt, device=dev)
+                eng.emb_cur_all = torch.empty((nb, D), dtype=dt, device=dev)
+            if len(self._engines) >= 4:
+                self._engines.pop(next(iter(self._engines)))
+            self._engines[key] = eng
+        # ---- load this call's inputs into the static buffers (device-to-device copies; graphs keep their pointers)
+        eng.lat.copy_(lat)
+        lat = eng.lat
+        eng.ehs.copy_(ehs)
+        eng.emb_main.copy_(emb_main)
+        eng.coef = self.scheduler.coef_table(dev) if getattr(eng, "coef", None) is None else eng.coef
+        eng.step_idx.zero_()
+        for c in active:
+            eng.masks[c].copy_(masks[c])
+        xin, nout, step_idx, coef = eng.xin, eng.nout, eng.step_idx, eng.coef
         model_input, region_in = xin[:4], xin[4:]
         noise, region_noise = nout[:4], nout[4:]
         ops.scale_model_input(lat, self.scheduler.cin0(dev), model_input)
@@ -249,36 +283,76 @@ class LoraMultiConceptPipeline:
             region_list[c] = region_noise[2 * j: 2 * j + 2]
         main_kw = dict(cross_attention_kwargs or {})
         main_kw.pop("scale", None)
-        batched = fuse_possible and concept_models.bank is not None and concept_models.bank.mode == "merged"
+        if fuse_possible:
+            eng.c_ehs.copy_(c_ehs)
+            eng.emb_conc.copy_(emb_conc)
         if batched:
-            ehs_all = torch.cat([ehs, c_ehs], dim=0).contiguous()
-            emb_all = torch.cat([emb_main, emb_conc], dim=1).contiguous()             # (S, nb, D)
+            eng.ehs_all[:4].copy_(ehs)
+            eng.ehs_all[4:].copy_(c_ehs)
+            eng.emb_all[:, :4].copy_(emb_main)
+            eng.emb_all[:, 4:].copy_(emb_conc)
             state_all = concept_models.lora_state([0, 0, 0, 0] + [s + 1 for s in slots], merged=True)
             all_kw = dict(main_kw)
             all_kw["omg_main_batch"] = 4
+        if use_graph:
+            # cached cross-attention K/V must be refreshed eagerly: replayed graphs read the stored projections
+            self.unet.refresh_cross_kv(eng.ehs, None)
+            if batched:
+                self.unet.refresh_cross_kv(eng.ehs_all, state_all)
 
-        def one_step(i: int, fused: bool):
+        def step_body(fused: bool):
+            """One denoising iteration; every per-step quantity is selected by the DEVICE step counter."""
             if fused and batched:
                 region_in.copy_(model_input[3:4].expand(2 * Ka, -1, -1, -1))      # latent_model_input[3:4] duplicated (:583-585)
+                ops.gather_step(eng.emb_all, step_idx, eng.emb_cur_all)
                 self.unet.set_lora_state(state_all)
                 try:
-                    self.unet(xin, None, encoder_hidden_states=ehs_all, cross_attention_kwargs=all_kw, emb=emb_all[i], out=nout)
+                    self.unet(xin, None, encoder_hidden_states=eng.ehs_all, cross_attention_kwargs=all_kw, emb=eng.emb_cur_all, out=nout)
                 finally:
                     self.unet.set_lora_state(None)
             else:
-                self.unet(model_input, None, encoder_hidden_states=ehs, cross_attention_kwargs=main_kw, emb=emb_main[i], out=noise)
+                ops.gather_step(eng.emb_main, step_idx, eng.emb_cur_main)
+                self.unet(model_input, None, encoder_hidden_states=eng.ehs, cross_attention_kwargs=main_kw, emb=eng.emb_cur_main, out=noise)
                 if fused:
                     region_in.copy_(model_input[3:4].expand(2 * Ka, -1, -1, -1))
-                    concept_models.unet_batched(region_in, None, c_ehs, slots, emb=emb_conc[i], out=region_noise)
+                    ops.gather_step(eng.emb_conc, step_idx, eng.emb_cur_conc)
+                    concept_models.unet_batched(region_in, None, eng.c_ehs, slots, emb=eng.emb_cur_conc, out=region_noise)
             ops.fuse_cfg_step(noise, lat, coef, step_idx, guidance_scale=guidance_scale, fuse=fused,
-                              region_preds=region_list if fused else [None] * K, masks=masks if fused else [None] * K,
+                              region_preds=region_list if fused else [None] * K, masks=eng.masks if fused else [None] * K,
                               model_input_next=model_input, advance=True)
+
+        def run_step(i: int):
+            fused = fuse_possible and i > fusion_start
+            if not use_graph:
+                step_body(fused)
+                return
+            win = controller._self_window() if controller is not None and hasattr(controller, "_self_window") else None
+            regime = (fused, win)
+            g = eng.graphs.get(regime)
+            if g is not None:
+                g.replay()
+                if controller is not None:
+                    controller.cur_step += 1          # the replayed graph does not run the host-side counters
+                return
+            if regime not in eng.warmed:              # first step of a regime runs eagerly (lazy inits, caches)
+                step_body(fused)
+                eng.warmed.add(regime)
+                return
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, pool=eng.pool):
+                step_body(fused)                      # records the step; host counters tick as in eager mode
+            if eng.pool is None:
+                eng.pool = g.pool()
+            eng.graphs[regime] = g
+            g.replay()
 
         # ---- 8. denoising loop
         for i in range(S):
-            one_step(i, fuse_possible and i > fusion_start)
+            run_step(i)
             if trajectory is not None:
                 trajectory.append(lat.clone())
+        lat = lat.clone()
         if output_type == "latent":
             images = lat
         else:

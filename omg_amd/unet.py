@@ -356,6 +356,17 @@ class UNet2DConditionModel(nn.Module):
         for m in self._linears:
             m.lora_state = state
 
+    def refresh_cross_kv(self, ctx: torch.Tensor, state: Optional[LoraState]) -> None:
+        """Recompute the cached cross-attention K / V^T of every attn2 for ``ctx`` (in place when the shape was seen
+        before, so captured graphs stay valid).  Called eagerly before replaying step graphs on new inputs."""
+        self.set_lora_state(state)
+        try:
+            for _, m in self.attentions():
+                if m.is_cross:
+                    m.project_cross(ctx)
+        finally:
+            self.set_lora_state(None)
+
     # ------------------------------------------------------------------ forward
     def _boundary_weights(self):
         if not self._boundary:

@@ -105,3 +105,45 @@ def test_two_stage_loop_matches_oracle(dev, sched, lora_mode):
         else:
             assert (ref[1] - stage1[1]).abs().max() > 0.1, "fusion must change the edited sample"
             assert torch.allclose(ref[0], stage1[0], atol=1e-5), "the base sample never depends on the edit"
+
+
+def test_graph_replay_is_bitwise_equal_to_eager(dev):
+    """hipGraph path: static buffers + captured step graphs (3 regimes) vs the eager loop, two different images
+    through the SAME engine (second image replays every step)."""
+    dtype = torch.float16
+    cfg, ocfg, sd, unet = setup(dev, dtype)
+    L = cfg.sample_size
+    S, gs, fstart = 10, 7.5, 3
+    H = W = L * 8
+    names = ou.lora_target_names(ocfg)
+    bank = LoraBank(unet, [LoraAdapter(f"c{c}", {k: (a.to(dev), b.to(dev)) for k, (a, b) in ou.make_lora(ocfg, names, 8, 100 + c, 0.8, dtype)[0].items()}) for c in range(2)])
+    concept = ConceptModels(unet, bank)
+    pctl = pc.AttentionReplace([P, P], S, {"default_": 1.0}, 0.5, L // 4, L // 4, device=dev)
+    revise_regionally_controlnet_forward(unet, pctl)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
+    m1 = torch.zeros(H, W); m1[H // 4:, : W // 2] = 1
+    m2 = torch.zeros(H, W); m2[H // 4:, W // 2 - 16:] = 1
+
+    def run(seed, use_graph):
+        pe1, pp1 = embeds(cfg, 1, seed, dtype); ne1, np1 = embeds(cfg, 1, seed + 50, dtype)
+        regions = []
+        for c in range(2):
+            re_, rp_ = embeds(cfg, 2, seed + 10 + c, dtype)
+            regions.append((re_[0:1], re_[1:2], rp_[0:1], rp_[1:2]))
+        lat0 = torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(seed))
+        pctl.reset()
+        traj = []
+        pipe(prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
+             negative_pooled_prompt_embeds=np1.repeat(2, 1), height=H, width=W, num_inference_steps=S, guidance_scale=gs, latents=lat0,
+             cross_attention_kwargs={"scale": 0.8}, controller=pctl, concept_models=concept, stage=2, region_masks=[m1, m2],
+             lora_list=["c0", "c1"], styleL=False, region_prompt_embeds=regions, trajectory=traj, fusion_start=fstart, use_graph=use_graph)
+        assert (pctl.cur_step, pctl.cur_att_layer) == (S, 0)
+        return [t.cpu() for t in traj]
+
+    eager = [run(seed, False) for seed in (1, 2)]
+    graph = [run(seed, True) for seed in (1, 2)]       # image 1 captures, image 2 is pure replay
+    graph.append(run(1, True))                          # and back to image 1 through the same graphs
+    for a, b in ((eager[0], graph[0]), (eager[1], graph[1]), (eager[0], graph[2])):
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), f"step {i}: graph replay differs from eager by {(x - y).abs().max().item()}"
+    assert not torch.equal(eager[0][-1], eager[1][-1])
