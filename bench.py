@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-latent", type=int, default=64, choices=[64, 128])
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (NOT a valid benchmark)")
+    ap.add_argument("--images-per-step", type=int, default=1, help="independent requests run in lock-step per step (one batched UNet forward)")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
 
@@ -100,38 +101,46 @@ def main():
     concept = make_concept_models(unet, n_concepts=2, rank=64 if not args.tiny else 8)
     pipe = LoraMultiConceptPipeline(unet, make_scheduler(args.scheduler))
     masks = c2_masks(HW, HW, device=dev)
-    n_img = args.warmup + args.steps
-    inputs = [c2_inputs(unet, seed=rank * 1000 + i, height=HW, width=HW) for i in range(n_img)]   # resident in HBM
+    n_steps = args.warmup + args.steps
+    ips = args.images_per_step
+    inputs = []
+    for i in range(n_steps):                                                                       # resident in HBM
+        reqs = []
+        for j in range(ips):
+            r = c2_inputs(unet, seed=(rank * 1000 + i) * 16 + j, height=HW, width=HW)
+            r["region_masks"] = masks
+            reqs.append(r)
+        inputs.append(reqs)
 
-    def run_image(inp, **kw):
+    def run_step(reqs):
+        """One bench step = `ips` complete stage-2 calls (independent requests batched through the UNet in lock-step)."""
         ctl.reset()                                                                   # inference_lora.py:274
-        return pipe(height=HW, width=HW, num_inference_steps=args.denoise_steps, guidance_scale=7.5,
-                    cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
-                    region_masks=masks, lora_list=["concept0", "concept1"], styleL=False, output_type="latent",
-                    use_graph=not args.no_graph, **inp, **kw).images
+        return pipe.generate_many(reqs, height=HW, width=HW, num_inference_steps=args.denoise_steps, guidance_scale=7.5,
+                                  cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
+                                  lora_list=["concept0", "concept1"], styleL=False, use_graph=not args.no_graph)
 
     for i in range(args.warmup):
-        lat = run_image(inputs[i])
-        parallel.gather_latents(lat[1:2], world, rank, world)
+        lat = run_step(inputs[i])
+        parallel.gather_latents(lat[:, 1].contiguous(), world * ips, rank, world)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_img):
-        lat = run_image(inputs[i])
-        allimg = parallel.gather_latents(lat[1:2].contiguous(), world, rank, world)  # the deliverable is images[1]
+    for i in range(args.warmup, n_steps):
+        lat = run_step(inputs[i])
+        allimg = parallel.gather_latents(lat[:, 1].contiguous(), world * ips, rank, world)       # the deliverable is images[1]
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     assert torch.isfinite(allimg).all()
-    value = world * args.steps / el
+    value = world * ips * args.steps / el
 
     out = {"metric": "images/sec @ SDXL 1024^2 50-step, 2-concept mask fusion", "value": value, "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * el / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: SDXL-base 1024x1024, %d %s steps, 2 concepts + 2 rank-64 LoRAs, masked "
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),
-                      "global_batch": world, "main_batch": 4, "concept_batch": 4, "accounting": "stage-2 only, as executed by the reference "
+                      "global_batch": world * ips, "images_per_step_per_gpu": ips, "main_batch": 4 * ips, "concept_batch": 4 * ips, "accounting": "stage-2 only, as executed by the reference "
                       "(200 main + 136 concept sample-forwards = 2.273 PFLOP/image); no redundancy shortcuts",
                       "parallelism": f"dp{world}", "tiny_debug": bool(args.tiny),
                       "step_loop": "eager" if args.no_graph else "hipGraph replay (3 captured step regimes)", "lora": "merged weight slots, "
@@ -144,9 +153,9 @@ def main():
         prof = ops.KernelProfiler()
         ops.set_profiler(prof)
         ctl.reset()
-        pipe(height=HW, width=HW, num_inference_steps=4, guidance_scale=7.5, cross_attention_kwargs={"scale": 0.8},
-             controller=ctl, concept_models=concept, stage=2, region_masks=masks, lora_list=["concept0", "concept1"],
-             styleL=False, output_type="latent", fusion_start=1, **inputs[0])
+        pipe.generate_many(inputs[0], height=HW, width=HW, num_inference_steps=4, guidance_scale=7.5,
+                           cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
+                           lora_list=["concept0", "concept1"], styleL=False, fusion_start=1)
         ops.set_profiler(None)
         torch.cuda.synchronize()
         summ = prof.summary()

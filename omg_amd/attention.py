@@ -187,7 +187,7 @@ class FusedAttnProcessor:
 
     supports_fused_residual = True
 
-    def _qk_src(self, attn, is_cross: bool, n_tokens: int, batch: int, device, main_batch=None):
+    def _qk_src(self, attn, is_cross: bool, n_tokens: int, batch: int, device, main_batch=None, images=1):
         return None
 
     def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
@@ -203,8 +203,9 @@ class FusedAttnProcessor:
         else:
             q, k, vt = attn.project_self(x)
         bypass = cross_attention_kwargs.pop("omg_bypass_controller", False)
-        main_b = cross_attention_kwargs.pop("omg_main_batch", None)       # first `main_b` samples are the p2p batch
-        src = None if bypass else self._qk_src(attn, is_cross, N, B, x.device, main_b)
+        main_b = cross_attention_kwargs.pop("omg_main_batch", None)       # p2p batch per request [unc0,unc1,cond0,cond1]
+        n_img = cross_attention_kwargs.pop("omg_images", 1)               # requests batched in lock-step
+        src = None if bypass else self._qk_src(attn, is_cross, N, B, x.device, main_b, n_img)
         o = ops.attention(q, k, vt, attn.heads, attn.scale, qk_src=src)
         out = attn.to_out[0](o, residual=residual)
         return out
@@ -221,11 +222,11 @@ class RegionControlNet_AttnProcessor(FusedAttnProcessor):
     def _fusable(self) -> bool:
         return self.controller is None or getattr(self.controller, "is_pure_replacement", False)
 
-    def _qk_src(self, attn, is_cross, n_tokens, batch, device, main_batch=None):
+    def _qk_src(self, attn, is_cross, n_tokens, batch, device, main_batch=None, images=1):
         if self.controller is None:
             return None
         return self.controller.fused_qk_src(is_cross, n_tokens, main_batch or batch, self.place_in_unet, device=device,
-                                            total_batch=batch)
+                                            total_batch=batch, images=images)
 
     def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  scale: float = 1.0, residual: Optional[torch.Tensor] = None, **cross_attention_kwargs):
@@ -233,6 +234,8 @@ class RegionControlNet_AttnProcessor(FusedAttnProcessor):
             return super().__call__(attn, hidden_states, encoder_hidden_states, attention_mask, temb, scale,
                                     residual=residual, **cross_attention_kwargs)
         # ---- protocol mode: the reference's literal sequence (lora_pipeline.py:98-124)
+        if cross_attention_kwargs.get("omg_images", 1) != 1:
+            raise L.OmgHipError("protocol mode (non-identity mapper) runs one request at a time")
         x = _to_tokens(attn, hidden_states)
         is_cross = encoder_hidden_states is not None
         src = encoder_hidden_states if is_cross else x

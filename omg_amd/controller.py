@@ -200,26 +200,30 @@ class AttentionReplace:
             return True
         return self._self_window() and n_tokens <= self.width * self.height
 
-    def qk_src_vector(self, batch: int, device, total_batch: Optional[int] = None) -> torch.Tensor:
-        """[0..n-1 | n, n, ...]: every conditional sample borrows Q,K from the first conditional one.
-        ``batch`` = 2 * len(prompts) in the reference's layout [unc_0..unc_{n-1}, cond_0..cond_{n-1}];
-        samples beyond ``batch`` (concept passes batched behind the p2p batch) keep their own Q,K."""
-        total = total_batch or batch
-        key = (batch, total, str(device))
+    def qk_src_vector(self, batch: int, device, total_batch: Optional[int] = None, images: int = 1) -> torch.Tensor:
+        """Per request [0..n-1 | n, n, ...]: every conditional sample borrows Q,K from the first conditional one.
+        ``batch`` = 2 * len(prompts) in the reference's layout [unc_0..unc_{n-1}, cond_0..cond_{n-1}]; ``images``
+        such blocks follow each other; samples beyond them (concept passes batched behind) keep their own Q,K."""
+        total = total_batch or batch * images
+        key = (batch, total, images, str(device))
         t = self._src_cache.get(key)
         if t is None:
             n = batch // 2
-            t = torch.tensor(list(range(n)) + [n] * (batch - n) + list(range(batch, total)), dtype=torch.int32, device=device)
+            v = []
+            for j in range(images):
+                v += [j * batch + i for i in range(n)] + [j * batch + n] * (batch - n)
+            v += list(range(batch * images, total))
+            t = torch.tensor(v, dtype=torch.int32, device=device)
             self._src_cache[key] = t
         return t
 
     def fused_qk_src(self, is_cross: bool, n_tokens: int, batch: int, place_in_unet: str = "",
-                     device=None, total_batch: Optional[int] = None) -> Optional[torch.Tensor]:
+                     device=None, total_batch: Optional[int] = None, images: int = 1) -> Optional[torch.Tensor]:
         if not self.is_pure_replacement:
             raise RuntimeError("fused_qk_src needs a pure-replacement controller (identity mapper, alpha == 1)")
         if batch != 2 * self.batch_size:
             raise ValueError(f"controller built for {self.batch_size} prompts expects a batch of {2 * self.batch_size} "
                              f"([unc..., cond...]), got {batch}")
-        src = self.qk_src_vector(batch, device or self.device or "cuda", total_batch) if self.replaces(is_cross, n_tokens) else None
+        src = self.qk_src_vector(batch, device or self.device or "cuda", total_batch, images) if self.replaces(is_cross, n_tokens) else None
         self._tick()
         return src

@@ -584,58 +584,35 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
   for (int s = 0; s < NST3 - 1; ++s)
     if (s < nk) issue(s);
 
-  // Software-pipelined main loop: the ONE barrier per stage sits between the two k-steps, and every
-  // ds_read_b128 batch is issued one k-step ahead of the MFMAs that consume it (two fragment sets in
-  // registers), so LDS latency and the DMA issue are always covered by this wave's own MFMAs.
-  //   [F0 = frags(kt, ks0) ready]  read F1 = (kt, ks1) | MFMA F0 | wait stage kt+1, barrier, DMA stage kt+NST-1
-  //                                read F0 = (kt+1, ks0) | MFMA F1
-  V8 af0[MT], bf0[NT], af1[MT], bf1[NT];
-  {
-    const int inflight = (nk - 1) < (NST3 - 2) ? (nk - 1) : (NST3 - 2);
-    if (inflight >= 2) wait_vmcnt<2 * NDMA>();
-    else if (inflight == 1) wait_vmcnt<NDMA>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bf0[j] = *(const V8*)(smem + bro[j][0]);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) af0[i] = *(const V8*)(smem + aro[i][0]);
-  }
+  // Main loop: counted wait for stage kt, ONE barrier, DMA three stages ahead, then 2 k-steps of MFMAs.
+  // (A variant with the barrier between the two k-steps and fragment reads issued one k-step ahead measured
+  //  2-5 % slower on MI355X: the compiler already overlaps the second k-step's ds_reads with the first's MFMAs.)
   for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = nk - 1 - kt;         // later stages whose DMA may stay in flight: min(ahead, NST3 - 2)
+    if (!(p.dbg & 2)) {
+      if (NST3 >= 4 && ahead >= 2) wait_vmcnt<2 * NDMA>();
+      else if (ahead >= 1) wait_vmcnt<NDMA>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    if (kt + NST3 - 1 < nk && !(p.dbg & 1)) issue(kt + NST3 - 1);
     const char* sb = smem + (kt % NST3) * STAGE_BYTES;
-    if (!(p.dbg & 4)) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf1[j] = *(const V8*)(sb + bro[j][1]);
+    for (int ks = 0; ks < 2; ++ks) {
+      V8 af[MT], bf[NT];
+      if (!(p.dbg & 4) || kt == 0) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af1[i] = *(const V8*)(sb + aro[i][1]);
-    }
+        for (int j = 0; j < NT; ++j) bf[j] = *(const V8*)(sb + bro[j][ks]);
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af0[i], bf0[j], acc[i][j]);
-    if (kt + 1 < nk) {
-      // stage kt+1 must have landed; stages up to kt+NST-2 have been issued
-      const int later = nk - 2 - kt;                       // stages beyond kt+1 that exist
-      if (!(p.dbg & 2)) {
-        if (NST3 >= 4 && later >= 1) wait_vmcnt<NDMA>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + aro[i][ks]);
       }
-      if (kt + NST3 - 1 < nk && !(p.dbg & 1)) issue(kt + NST3 - 1);
-      const char* sn = smem + ((kt + 1) % NST3) * STAGE_BYTES;
-      if (!(p.dbg & 4)) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf0[j] = *(const V8*)(sn + bro[j][0]);
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af0[i] = *(const V8*)(sn + aro[i][0]);
-      }
+        for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[i], bf[j], acc[i][j]);
     }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af1[i], bf1[j], acc[i][j]);
   }
-
+  __syncthreads();
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
 

@@ -119,6 +119,10 @@ class StableDiffusionXLPipelineOutput(SimpleNamespace):
 
 
 class LoraMultiConceptPipeline:
+    """See the module docstring.  ``__call__`` keeps the reference's single-request signature; ``generate_many`` runs
+    several independent requests in lock-step through ONE batched UNet forward per step (images are independent,
+    SURVEY §8e) — same per-image arithmetic, larger GEMMs."""
+
     def __init__(self, unet, scheduler=None, encode_prompt: Optional[Callable] = None, vae_decode: Optional[Callable] = None):
         self.unet = unet
         self.scheduler = scheduler or DDIMScheduler()
@@ -150,7 +154,14 @@ class LoraMultiConceptPipeline:
         ids = list(original_size) + list(crops) + list(target_size)
         return torch.tensor([ids] * n, dtype=torch.float32, device=device)
 
-    # ------------------------------------------------------------------ the call
+    def _all_step_embeddings(self, ts: torch.Tensor, text: torch.Tensor, tids: torch.Tensor) -> torch.Tensor:
+        """emb[i] for every step in one batched pass: (S, B, 4*C0).  Depends only on (t_i, pooled text, time ids)."""
+        S, B = ts.numel(), text.shape[0]
+        t_all = ts.reshape(S, 1).expand(S, B).reshape(-1).contiguous()
+        emb = self.unet.time_embed(t_all, S * B, text.repeat(S, 1), tids.repeat(S, 1))
+        return emb.view(S, B, -1)
+
+    # ------------------------------------------------------------------ the reference's call signature
     @torch.no_grad()
     def __call__(self, prompt=None, prompt_2=None, image=None, height: Optional[int] = None, width: Optional[int] = None,
                  num_inference_steps: int = 50, guidance_scale: float = 5.0, negative_prompt=None, negative_prompt_2=None,
@@ -167,12 +178,7 @@ class LoraMultiConceptPipeline:
             raise L.OmgHipError("ControlNet conditioning (image=) is a 'next' row of SURVEY §8f (N2) and is not implemented")
         if eta != 0.0:
             raise L.OmgHipError("eta != 0 (stochastic DDIM) is not used by OMG and is not supported")
-        dev, dt = self.unet.device, self.unet.dtype
-        batch_size = 2                                                           # lora_pipeline.py:291
-        height = height or self.unet.config.sample_size * self.vae_scale_factor
-        width = width or self.unet.config.sample_size * self.vae_scale_factor
         lora_list = list(lora_list or [])
-        K = len(lora_list)
         # ---- 3. prompt embeddings (global on the main pipe; per-region on the concept pipe)
         if prompt_embeds is None:
             if self.encode_prompt is None:
@@ -185,35 +191,89 @@ class LoraMultiConceptPipeline:
             for lora_param, (rp, rn) in zip(lora_list, [(r[0], r[1]) for r in regions]):
                 pe, ne, pp, npp = self.encode_prompt(rp, rn, lora_param)
                 region_prompt_embeds.append((ne, pe, npp, pp))
-        if prompt_embeds.shape[0] != batch_size:
-            raise ValueError("prompt_embeds must hold the 2 global prompts [p, p] (lora_pipeline.py:291)")
-        if region_prompt_embeds is None:
-            region_prompt_embeds = []
-        if len(region_prompt_embeds) != K:
-            raise ValueError("one (neg_embeds, pos_embeds, neg_pooled, pos_pooled) tuple per entry of lora_list is required")
-        # ---- 5./6. timesteps and latents (duplicated x2, :409)
-        self.scheduler.set_timesteps(num_inference_steps, device=dev)
-        lat = self.prepare_latents(batch_size // 2 * num_images_per_prompt, self.unet.config.in_channels, height, width,
-                                   torch.float32, dev, generator, latents)
-        lat = torch.cat([lat, lat.clone()]).contiguous()
-        Hl, Wl = lat.shape[2:]
-        # ---- 7.2 added time ids, CFG concat order [neg, pos] (:467-474)
+        req = dict(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
+                   pooled_prompt_embeds=pooled_prompt_embeds, negative_pooled_prompt_embeds=negative_pooled_prompt_embeds,
+                   region_prompt_embeds=region_prompt_embeds, region_masks=region_masks, latents=latents, generator=generator)
+        traj_many = [] if trajectory is not None else None
+        lat = self.generate_many([req], height=height, width=width, num_inference_steps=num_inference_steps,
+                                 guidance_scale=guidance_scale, cross_attention_kwargs=cross_attention_kwargs,
+                                 original_size=original_size, crops_coords_top_left=crops_coords_top_left, target_size=target_size,
+                                 controller=controller, concept_models=concept_models, stage=stage, lora_list=lora_list,
+                                 styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
+                                 lora_mode=lora_mode)[0]
+        if trajectory is not None:
+            trajectory.extend(t[0] for t in traj_many)
+        if output_type == "latent":
+            images = lat
+        else:
+            if self.vae_decode is None:
+                raise L.OmgHipError("VAE decode is a 'next' row (SURVEY §8f N1): use output_type='latent' or pass vae_decode=")
+            images = self.vae_decode(lat)
+        if not return_dict:
+            return (images,)
+        return StableDiffusionXLPipelineOutput(images=images)
+
+    # ------------------------------------------------------------------ n independent requests in lock-step
+    @torch.no_grad()
+    def generate_many(self, requests: Sequence[dict], *, height: Optional[int] = None, width: Optional[int] = None,
+                      num_inference_steps: int = 50, guidance_scale: float = 5.0, cross_attention_kwargs=None,
+                      original_size=None, crops_coords_top_left=(0, 0), target_size=None, controller=None,
+                      concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None,
+                      lora_list: Optional[Sequence[str]] = None, styleL: Optional[bool] = None, use_graph: bool = False,
+                      trajectory: Optional[list] = None, fusion_start: int = FUSION_START, lora_mode: str = "merged") -> torch.Tensor:
+        """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
+        negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
+        latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
+        All requests must agree on which concepts have a mask."""
+        dev, dt = self.unet.device, self.unet.dtype
+        n = len(requests)
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        lora_list = list(lora_list or [])
+        K = len(lora_list)
+        S = num_inference_steps
+        self.scheduler.set_timesteps(S, device=dev)
+        ts = self.scheduler.timesteps.to(torch.float32)
         original_size = original_size or (height, width)
         target_size = target_size or (height, width)
-        ehs = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(device=dev, dtype=dt).contiguous()
-        text = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds], dim=0).to(device=dev, dtype=dt)
-        tids = self._add_time_ids(original_size, crops_coords_top_left, target_size, 2 * batch_size, dev)
-        S = num_inference_steps
-        ts = self.scheduler.timesteps.to(torch.float32)
-        emb_main = self._all_step_embeddings(ts, text, tids)                       # (S, 4, D)
-        # ---- concepts that take part (mask is not None), batched with per-sample LoRA slots
-        masks: List[Optional[torch.Tensor]] = [None] * K
-        if stage == 2:
-            if region_masks is None or len(region_masks) != K:
-                raise ValueError("stage 2 needs one region mask (or None) per entry of lora_list")
-            masks = [m.to(device=dev, dtype=torch.float32).contiguous() if m is not None else None for m in region_masks]
-        active = [c for c in range(K) if masks[c] is not None]
-        fuse_possible = stage == 2 and len(active) > 0 and S > fusion_start + 1
+        Cl = self.unet.config.in_channels
+        # ---- per-request tensors
+        lats, ehs_l, text_l, masks_l, cehs_l, ctext_l = [], [], [], [], [], []
+        active = None
+        for r in requests:
+            pe, ne = r["prompt_embeds"], r["negative_prompt_embeds"]
+            if pe.shape[0] != 2:
+                raise ValueError("prompt_embeds must hold the 2 global prompts [p, p] (lora_pipeline.py:291)")
+            lat0 = self.prepare_latents(1, Cl, height, width, torch.float32, dev, r.get("generator"), r.get("latents"))
+            lats.append(torch.cat([lat0, lat0.clone()]))                                            # duplicated x2 (:409)
+            ehs_l.append(torch.cat([ne, pe], dim=0).to(device=dev, dtype=dt))                       # CFG order [neg, pos] (:467-474)
+            text_l.append(torch.cat([r["negative_pooled_prompt_embeds"], r["pooled_prompt_embeds"]], dim=0).to(device=dev, dtype=dt))
+            rpe = r.get("region_prompt_embeds") or []
+            if len(rpe) != K:
+                raise ValueError("one (neg_embeds, pos_embeds, neg_pooled, pos_pooled) tuple per entry of lora_list is required")
+            masks = [None] * K
+            if stage == 2:
+                rm = r.get("region_masks")
+                if rm is None or len(rm) != K:
+                    raise ValueError("stage 2 needs one region mask (or None) per entry of lora_list")
+                masks = [m.to(device=dev, dtype=torch.float32).contiguous() if m is not None else None for m in rm]
+            act = [c for c in range(K) if masks[c] is not None]
+            if active is None:
+                active = act
+            elif act != active:
+                raise ValueError("requests batched together must have masks for the same concepts")
+            masks_l.append(masks)
+            if act:
+                cehs_l.append(torch.cat([torch.cat([rpe[c][0], rpe[c][1]], dim=0) for c in act], dim=0).to(device=dev, dtype=dt))
+                ctext_l.append(torch.cat([torch.cat([rpe[c][2], rpe[c][3]], dim=0) for c in act], dim=0).to(device=dev, dtype=dt))
+        Ka = len(active)
+        Hl, Wl = lats[0].shape[2:]
+        fuse_possible = stage == 2 and Ka > 0 and S > fusion_start + 1
+        nm, ncn = 4 * n, 2 * Ka * n                       # rows of the main block / the concept block
+        nb = nm + (ncn if fuse_possible else 0)
+        ehs = torch.cat(ehs_l, dim=0).contiguous()                                                  # (4n, 77, Cx)
+        emb_main = self._all_step_embeddings(ts, torch.cat(text_l, dim=0),
+                                             self._add_time_ids(original_size, crops_coords_top_left, target_size, nm, dev))
         slots: List[int] = []
         if fuse_possible:
             if concept_models is None:
@@ -224,40 +284,35 @@ class LoraMultiConceptPipeline:
                 bank = concept_models.bank
                 if [tuple(c) for c in combos] != list(bank.slots) or bank.scale != scale or bank.mode != lora_mode:
                     bank.build(combos, scale=scale, mode=lora_mode)
-                slots = [s for s in range(len(active)) for _ in range(2)]
+                slots = [s for _ in range(n) for s in range(Ka) for _ in range(2)]
             else:
-                slots = [-1] * (2 * len(active))
-            c_ehs = torch.cat([torch.cat([region_prompt_embeds[c][0], region_prompt_embeds[c][1]], dim=0) for c in active], dim=0)
-            c_ehs = c_ehs.to(device=dev, dtype=dt).contiguous()                   # (2Ka, 77, Cx) = [unc, cond] per concept
-            c_text = torch.cat([torch.cat([region_prompt_embeds[c][2], region_prompt_embeds[c][3]], dim=0) for c in active], dim=0)
-            c_tids = self._add_time_ids(original_size, crops_coords_top_left, target_size, 2 * len(active), dev)
-            emb_conc = self._all_step_embeddings(ts, c_text.to(device=dev, dtype=dt), c_tids)   # (S, 2Ka, D)
-        # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
-        Ka = len(active)
-        nb = 4 + 2 * Ka
-        Cl = lat.shape[1]
+                slots = [-1] * ncn
+            c_ehs = torch.cat(cehs_l, dim=0).contiguous()                                           # (2Ka*n, 77, Cx)
+            emb_conc = self._all_step_embeddings(ts, torch.cat(ctext_l, dim=0),
+                                                 self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev))
         batched = fuse_possible and concept_models.bank is not None and concept_models.bank.mode == "merged"
         if use_graph and fuse_possible and not batched:
             raise L.OmgHipError("use_graph needs lora_mode='merged' (segment-mode K/V projections are not pointer-stable)")
-        mshape = tuple(masks[active[0]].shape) if active else (0, 0)
+        mshape = tuple(masks_l[0][active[0]].shape) if active else (0, 0)
         D = emb_main.shape[-1]
-        key = (S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
+        # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
+        key = (n, S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
                str(dt), batched, bool(styleL), tuple(lora_list), mshape, tuple(ehs.shape), id(controller))
         eng = self._engines.get(key)
         if eng is None:
-            eng = SimpleNamespace(graphs={}, warmed=set(), pool=None)
-            eng.lat = torch.empty((2, Cl, Hl, Wl), dtype=torch.float32, device=dev)
+            eng = SimpleNamespace(graphs={}, warmed=set(), pool=None, coef=None)
+            eng.lat = torch.empty((2 * n, Cl, Hl, Wl), dtype=torch.float32, device=dev)
             eng.xin = torch.empty((nb, Cl, Hl, Wl), dtype=dt, device=dev)
             eng.nout = torch.empty((nb, Cl, Hl, Wl), dtype=torch.float32, device=dev)
             eng.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
             eng.ehs = torch.empty_like(ehs)
-            eng.emb_main = torch.empty((S, 4, D), dtype=dt, device=dev)
-            eng.emb_cur_main = torch.empty((4, D), dtype=dt, device=dev)
-            eng.masks = [torch.empty(mshape, dtype=torch.float32, device=dev) if c in active else None for c in range(K)]
+            eng.emb_main = torch.empty((S, nm, D), dtype=dt, device=dev)
+            eng.emb_cur_main = torch.empty((nm, D), dtype=dt, device=dev)
+            eng.masks = [[torch.empty(mshape, dtype=torch.float32, device=dev) if c in active else None for c in range(K)] for _ in range(n)]
             if fuse_possible:
                 eng.c_ehs = torch.empty_like(c_ehs)
-                eng.emb_conc = torch.empty((S, 2 * Ka, D), dtype=dt, device=dev)
-                eng.emb_cur_conc = torch.empty((2 * Ka, D), dtype=dt, device=dev)
+                eng.emb_conc = torch.empty((S, ncn, D), dtype=dt, device=dev)
+                eng.emb_cur_conc = torch.empty((ncn, D), dtype=dt, device=dev)
             if batched:
                 eng.ehs_all = torch.empty((nb,) + tuple(ehs.shape[1:]), dtype=dt, device=dev)
                 eng.emb_all = torch.empty((S, nb, D), dtype=dt, device=dev)
@@ -266,60 +321,73 @@ class LoraMultiConceptPipeline:
                 self._engines.pop(next(iter(self._engines)))
             self._engines[key] = eng
         # ---- load this call's inputs into the static buffers (device-to-device copies; graphs keep their pointers)
-        eng.lat.copy_(lat)
         lat = eng.lat
+        lat.copy_(torch.cat(lats, dim=0))
         eng.ehs.copy_(ehs)
         eng.emb_main.copy_(emb_main)
-        eng.coef = self.scheduler.coef_table(dev) if getattr(eng, "coef", None) is None else eng.coef
+        if eng.coef is None:
+            eng.coef = self.scheduler.coef_table(dev)
         eng.step_idx.zero_()
-        for c in active:
-            eng.masks[c].copy_(masks[c])
+        for j in range(n):
+            for c in active:
+                eng.masks[j][c].copy_(masks_l[j][c])
         xin, nout, step_idx, coef = eng.xin, eng.nout, eng.step_idx, eng.coef
-        model_input, region_in = xin[:4], xin[4:]
-        noise, region_noise = nout[:4], nout[4:]
-        ops.scale_model_input(lat, self.scheduler.cin0(dev), model_input)
-        region_list: List[Optional[torch.Tensor]] = [None] * K
-        for j, c in enumerate(active):
-            region_list[c] = region_noise[2 * j: 2 * j + 2]
+        cin0 = self.scheduler.cin0(dev)
+        for j in range(n):
+            ops.scale_model_input(lat[2 * j: 2 * j + 2], cin0, xin[4 * j: 4 * j + 4])
         main_kw = dict(cross_attention_kwargs or {})
         main_kw.pop("scale", None)
+        main_kw["omg_main_batch"] = 4
+        main_kw["omg_images"] = n
         if fuse_possible:
             eng.c_ehs.copy_(c_ehs)
             eng.emb_conc.copy_(emb_conc)
         if batched:
-            eng.ehs_all[:4].copy_(ehs)
-            eng.ehs_all[4:].copy_(c_ehs)
-            eng.emb_all[:, :4].copy_(emb_main)
-            eng.emb_all[:, 4:].copy_(emb_conc)
-            state_all = concept_models.lora_state([0, 0, 0, 0] + [s + 1 for s in slots], merged=True)
-            all_kw = dict(main_kw)
-            all_kw["omg_main_batch"] = 4
+            eng.ehs_all[:nm].copy_(ehs)
+            eng.ehs_all[nm:].copy_(c_ehs)
+            eng.emb_all[:, :nm].copy_(emb_main)
+            eng.emb_all[:, nm:].copy_(emb_conc)
+            state_all = concept_models.lora_state([0] * nm + [s + 1 for s in slots], merged=True)
         if use_graph:
             # cached cross-attention K/V must be refreshed eagerly: replayed graphs read the stored projections
             self.unet.refresh_cross_kv(eng.ehs, None)
             if batched:
                 self.unet.refresh_cross_kv(eng.ehs_all, state_all)
 
+        def region_rows(j):
+            return nm + 2 * Ka * j
+
+        def fill_region_inputs():
+            for j in range(n):                            # latent_model_input[3:4] duplicated (:583-585), per request
+                r0 = region_rows(j)
+                xin[r0: r0 + 2 * Ka].copy_(xin[4 * j + 3: 4 * j + 4].expand(2 * Ka, -1, -1, -1))
+
         def step_body(fused: bool):
             """One denoising iteration; every per-step quantity is selected by the DEVICE step counter."""
             if fused and batched:
-                region_in.copy_(model_input[3:4].expand(2 * Ka, -1, -1, -1))      # latent_model_input[3:4] duplicated (:583-585)
+                fill_region_inputs()
                 ops.gather_step(eng.emb_all, step_idx, eng.emb_cur_all)
                 self.unet.set_lora_state(state_all)
                 try:
-                    self.unet(xin, None, encoder_hidden_states=eng.ehs_all, cross_attention_kwargs=all_kw, emb=eng.emb_cur_all, out=nout)
+                    self.unet(xin, None, encoder_hidden_states=eng.ehs_all, cross_attention_kwargs=main_kw, emb=eng.emb_cur_all, out=nout)
                 finally:
                     self.unet.set_lora_state(None)
             else:
                 ops.gather_step(eng.emb_main, step_idx, eng.emb_cur_main)
-                self.unet(model_input, None, encoder_hidden_states=eng.ehs, cross_attention_kwargs=main_kw, emb=eng.emb_cur_main, out=noise)
+                self.unet(xin[:nm], None, encoder_hidden_states=eng.ehs, cross_attention_kwargs=main_kw, emb=eng.emb_cur_main, out=nout[:nm])
                 if fused:
-                    region_in.copy_(model_input[3:4].expand(2 * Ka, -1, -1, -1))
+                    fill_region_inputs()
                     ops.gather_step(eng.emb_conc, step_idx, eng.emb_cur_conc)
-                    concept_models.unet_batched(region_in, None, eng.c_ehs, slots, emb=eng.emb_cur_conc, out=region_noise)
-            ops.fuse_cfg_step(noise, lat, coef, step_idx, guidance_scale=guidance_scale, fuse=fused,
-                              region_preds=region_list if fused else [None] * K, masks=eng.masks if fused else [None] * K,
-                              model_input_next=model_input, advance=True)
+                    concept_models.unet_batched(xin[nm:], None, eng.c_ehs, slots, emb=eng.emb_cur_conc, out=nout[nm:])
+            for j in range(n):
+                regs: List[Optional[torch.Tensor]] = [None] * K
+                if fused:
+                    for jj, c in enumerate(active):
+                        r0 = region_rows(j) + 2 * jj
+                        regs[c] = nout[r0: r0 + 2]
+                ops.fuse_cfg_step(nout[4 * j: 4 * j + 4], lat[2 * j: 2 * j + 2], coef, step_idx, guidance_scale=guidance_scale,
+                                  fuse=fused, region_preds=regs, masks=eng.masks[j] if fused else [None] * K,
+                                  model_input_next=xin[4 * j: 4 * j + 4], advance=(j == n - 1))
 
         def run_step(i: int):
             fused = fuse_possible and i > fusion_start
@@ -351,21 +419,5 @@ class LoraMultiConceptPipeline:
         for i in range(S):
             run_step(i)
             if trajectory is not None:
-                trajectory.append(lat.clone())
-        lat = lat.clone()
-        if output_type == "latent":
-            images = lat
-        else:
-            if self.vae_decode is None:
-                raise L.OmgHipError("VAE decode is a 'next' row (SURVEY §8f N1): use output_type='latent' or pass vae_decode=")
-            images = self.vae_decode(lat)
-        if not return_dict:
-            return (images,)
-        return StableDiffusionXLPipelineOutput(images=images)
-
-    def _all_step_embeddings(self, ts: torch.Tensor, text: torch.Tensor, tids: torch.Tensor) -> torch.Tensor:
-        """emb[i] for every step in one batched pass: (S, B, 4*C0).  Depends only on (t_i, pooled text, time ids)."""
-        S, B = ts.numel(), text.shape[0]
-        t_all = ts.reshape(S, 1).expand(S, B).reshape(-1).contiguous()
-        emb = self.unet.time_embed(t_all, S * B, text.repeat(S, 1), tids.repeat(S, 1))
-        return emb.view(S, B, -1)
+                trajectory.append(lat.clone().view(n, 2, Cl, Hl, Wl))
+        return lat.clone().view(n, 2, Cl, Hl, Wl)

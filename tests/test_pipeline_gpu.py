@@ -147,3 +147,44 @@ def test_graph_replay_is_bitwise_equal_to_eager(dev):
         for i, (x, y) in enumerate(zip(a, b)):
             assert torch.equal(x, y), f"step {i}: graph replay differs from eager by {(x - y).abs().max().item()}"
     assert not torch.equal(eager[0][-1], eager[1][-1])
+
+
+def test_generate_many_equals_single_requests(dev):
+    """Two requests in lock-step through one batched forward per step == the same requests run one at a time
+    (bitwise: every kernel is batch-invariant)."""
+    dtype = torch.float16
+    cfg, ocfg, sd, unet = setup(dev, dtype)
+    L = cfg.sample_size
+    S, gs, fstart = 6, 7.5, 2
+    H = W = L * 8
+    names = ou.lora_target_names(ocfg)
+    bank = LoraBank(unet, [LoraAdapter(f"c{c}", {k: (a.to(dev), b.to(dev)) for k, (a, b) in ou.make_lora(ocfg, names, 8, 100 + c, 0.8, dtype)[0].items()}) for c in range(2)])
+    concept = ConceptModels(unet, bank)
+    pctl = pc.AttentionReplace([P, P], S, {"default_": 1.0}, 0.5, L // 4, L // 4, device=dev)
+    revise_regionally_controlnet_forward(unet, pctl)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
+
+    def request(seed):
+        pe1, pp1 = embeds(cfg, 1, seed, dtype); ne1, np1 = embeds(cfg, 1, seed + 50, dtype)
+        regions = []
+        for c in range(2):
+            re_, rp_ = embeds(cfg, 2, seed + 10 + c, dtype)
+            regions.append((re_[0:1], re_[1:2], rp_[0:1], rp_[1:2]))
+        m1 = torch.zeros(H, W); m1[H // 4:, : W // 2 + 8 * seed] = 1
+        m2 = torch.zeros(H, W); m2[H // 8 * seed:, W // 2 - 16:] = 1
+        return dict(prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
+                    negative_pooled_prompt_embeds=np1.repeat(2, 1), region_prompt_embeds=regions, region_masks=[m1, m2],
+                    latents=torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(seed)))
+
+    common = dict(height=H, width=W, num_inference_steps=S, guidance_scale=gs, cross_attention_kwargs={"scale": 0.8}, controller=pctl,
+                  concept_models=concept, stage=2, lora_list=["c0", "c1"], styleL=False, fusion_start=fstart)
+    singles = []
+    for seed in (1, 2, 3):
+        pctl.reset()
+        singles.append(pipe.generate_many([request(seed)], **common)[0].cpu())
+    for use_graph in (False, True):
+        pctl.reset()
+        many = pipe.generate_many([request(1), request(2), request(3)], use_graph=use_graph, **common).cpu()
+        assert (pctl.cur_step, pctl.cur_att_layer) == (S, 0)
+        for j in range(3):
+            assert torch.equal(many[j], singles[j]), f"request {j} (graph={use_graph}): max diff {(many[j] - singles[j]).abs().max().item()}"
