@@ -4,13 +4,16 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one image = one complete stage-2 call of the reference's pipeline at BASELINE config 2:
+One "step" = one batch of `--images-per-step` (default 4) independent requests, each a complete stage-2 call of the
+reference's pipeline at BASELINE config 2 (4 per GPU is BASELINE configs[3]'s per-GPU share: "batch=32 sharded over 8 GPUs");
+the requests advance in lock-step through ONE batched UNet forward per denoising step, bitwise equal to running them one
+at a time (tests/test_pipeline_gpu.py).  Per request:
 SDXL-base UNet (2.567 B params, random init), 1024x1024 (latent 128x128), 50 DDIM steps, global batch
 [unc0,unc1,cond0,cond1], prompt-to-prompt controller installed (140 attention layers), 2 concepts with
 rank-64 LoRAs on every attention/FF Linear, overlapping region masks, fusion for steps i > 15
 (= 200 main + 136 concept UNet sample-forwards, 2.273 PFLOP algorithmic).
-Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, each rank runs K images
-(weak scaling), final latents all-gathered over RCCL per image; value = N*K / max-over-ranks time.
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU, each rank runs K steps
+(weak scaling), final latents all-gathered over RCCL per step; value = N * K * images_per_step / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (GEMM/conv kernel family, MFMA-bound, HIP-event
 timed in an instrumented pass of one plain + one fused denoising step) and "cpu_baseline" (the fp32 oracle on
@@ -74,7 +77,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-latent", type=int, default=64, choices=[64, 128])
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (NOT a valid benchmark)")
-    ap.add_argument("--images-per-step", type=int, default=1, help="independent requests run in lock-step per step (one batched UNet forward)")
+    ap.add_argument("--images-per-step", type=int, default=4, help="independent requests run in lock-step per step (one batched UNet forward)")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
 

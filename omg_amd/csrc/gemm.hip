@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = w * 32 + i * 8 + prow;
-      const int c = ppos ^ (r & 7);                    // source chunk for this LDS position
+      const int c = ppos ^ ((r >> 1) & 7);                    // source chunk for this LDS position
       const bool kvalid = (k0 + c * 8) < Kseg;
       // A operand
       const char* asrc;
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int ra = wm * 64 + i * 32 + l31;
-        af[i] = *(const V8*)(a_base + ra * 128 + ((kc ^ (ra & 7)) << 4));
+        af[i] = *(const V8*)(a_base + ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4));
         const int rb = wn * 64 + i * 32 + l31;
-        bf[i] = *(const V8*)(b_base + rb * 128 + ((kc ^ (rb & 7)) << 4));
+        bf[i] = *(const V8*)(b_base + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
