@@ -100,7 +100,7 @@ def main():
     P = "a man and a woman walking on the street"
     ctl = pc.AttentionReplace([P, P], 50, cross_replace_steps={"default_": 1.0}, self_replace_steps=0.4,
                               width=HW // 32, height=HW // 32, device=dev, dtype=dt)        # inference_lora.py:156,247
-    revise_regionally_controlnet_forward(unet, ctl) if rank == 0 else _quiet(revise_regionally_controlnet_forward, unet, ctl)
+    _quiet(revise_regionally_controlnet_forward, unet, ctl)       # the installer prints like the reference's; stdout must stay ONE JSON line
     concept = make_concept_models(unet, n_concepts=2, rank=64 if not args.tiny else 8)
     pipe = LoraMultiConceptPipeline(unet, make_scheduler(args.scheduler))
     masks = c2_masks(HW, HW, device=dev)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMG_ABI_VERSION 1
+#define OMG_ABI_VERSION 2
 
 enum { OMG_F16 = 0, OMG_BF16 = 1, OMG_F32 = 2 /* only where a signature says so */ };
 
@@ -114,6 +114,7 @@ typedef struct {
   const void* residual;       /* NHWC [B,Hout,Wout,Cout] or NULL                      */
   float out_scale;
   void* Y;                    /* NHWC [B,Hout,Wout,Cout]                              */
+  int32_t act;                /* OMG_ACT_NONE | OMG_ACT_SILU (ControlNetConditioningEmbedding)  */
 } omg_conv2d_args;
 
 int omg_conv2d(const omg_conv2d_args* a, void* stream);
@@ -190,6 +191,9 @@ int omg_conv_out(int dtype, const void* X_nhwc, int B, int H, int W, int Cin,
  * ---------------------------------------------------------------------- */
 int omg_timestep_embedding(int dtype, const float* t, int n, int dim, void* out, int64_t ldo, void* stream);
 int omg_silu(int dtype, const void* x, void* y, int64_t n, void* stream);
+/* y[i] += a[i]  (ControlNet residuals added to the UNet skip tensors: `sample += residual`,
+ * diffusers unet_2d_condition.py, reached from lora_pipeline.py:546-556) */
+int omg_add_inplace(int dtype, void* y, const void* a, int64_t n, void* stream);
 /* dst[r, col0 : col0+cols] = src[r, 0:cols]  (row-wise copy with strides, elements) */
 int omg_copy2d(int dtype, const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
 

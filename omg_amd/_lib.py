@@ -41,7 +41,7 @@ class Conv2dArgs(C.Structure):
         ("ksize", c_i32), ("stride", c_i32), ("upsample", c_i32),
         ("X1", c_vp), ("X2", c_vp), ("W", c_vp), ("bias", c_vp),
         ("group_bias", c_vp), ("ldgb", c_i64), ("residual", c_vp),
-        ("out_scale", c_f32), ("Y", c_vp),
+        ("out_scale", c_f32), ("Y", c_vp), ("act", c_i32),
     ]
 
 
@@ -81,6 +81,7 @@ SYMBOLS = {
     "omg_conv_out": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "omg_timestep_embedding": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "omg_silu": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "omg_add_inplace": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp]),
     "omg_copy2d": (c_i32, [c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "omg_fuse_cfg_step": (c_i32, [C.POINTER(StepArgs), c_vp]),
     "omg_scale_model_input": (c_i32, [c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
@@ -119,7 +120,7 @@ def lib() -> C.CDLL:
         fn = getattr(l, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if l.omg_abi_version() != 1:
+    if l.omg_abi_version() != 2:
         raise OmgHipError("libomg_hip.so ABI version mismatch; rebuild")
     v = os.environ.get("OMG_GEMM_VARIANT")      # debugging/benchmarking aid: force one GEMM tile configuration
     if v:

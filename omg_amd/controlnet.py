@@ -1,0 +1,179 @@
+"""SDXL ``ControlNetModel`` on the gfx950 kernels — row A13 of SURVEY.md §8a.
+
+Replaces the ``self.controlnet(...)`` / ``self.controlnet2(...)`` call sites of the reference
+(/root/reference src/pipelines/lora_pipeline.py:519-536; src/pipelines/instantid_pipeline.py:580-589 and :638-648,
+where the IdentityNet is a ControlNet fed with face tokens and a key-point image) with the same call contract:
+
+    controlnet(sample, t, encoder_hidden_states=, controlnet_cond=, conditioning_scale=, guess_mode=False,
+               added_cond_kwargs={"text_embeds","time_ids"}, return_dict=False) -> (down_block_res_samples[9], mid_block_res_sample)
+
+diffusers state-dict key layout (``controlnet_cond_embedding.*``, ``controlnet_down_blocks.N``, ``controlnet_mid_block``);
+the encoder blocks are the UNet's own classes.  MI355X-first details: the conditioning embedding does not depend on the
+step, so it is computed once per conditioning image and cached; its tiny channel counts (3/16/32/96) are zero-padded
+to 64 so that every convolution runs on the MFMA implicit-GEMM kernel with a fused SiLU epilogue; the 1x1 "zero"
+convolutions are GEMMs with ``conditioning_scale`` folded into the epilogue; residuals are returned as NCHW-shaped
+views of NHWC storage (torch channels_last), which the UNet adds to its skip tensors without any layout change.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .modules import Conv2d
+from .unet import (CrossAttnDownBlock2D, DownBlock2D, TimestepEmbedding, UNetConfig, UNetMidBlock2DCrossAttn, _Ctx)
+
+COND_CHANNELS = (16, 32, 96, 256)
+
+
+def _pad64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+class ControlNetConditioningEmbedding(nn.Module):
+    def __init__(self, out_channels: int, cond_in: int, dtype, device):
+        super().__init__()
+        self.conv_in = Conv2d(cond_in, COND_CHANNELS[0], 3, dtype=dtype, device=device)
+        self.blocks = nn.ModuleList()
+        for i in range(len(COND_CHANNELS) - 1):
+            self.blocks.append(Conv2d(COND_CHANNELS[i], COND_CHANNELS[i], 3, dtype=dtype, device=device))
+            self.blocks.append(Conv2d(COND_CHANNELS[i], COND_CHANNELS[i + 1], 3, stride=2, dtype=dtype, device=device))
+        self.conv_out = Conv2d(COND_CHANNELS[-1], out_channels, 3, dtype=dtype, device=device)
+        self._pk = {}
+
+    def invalidate_packed(self):
+        self._pk = {}
+
+    def _padded(self, name: str, conv: Conv2d, pad_out: bool):
+        """[Cout_p][3][3][Cin_p] weight and [Cout_p] bias with channels zero-padded to multiples of 64."""
+        if name not in self._pk:
+            w = conv.weight.data
+            co, ci = w.shape[:2]
+            cop = _pad64(co) if pad_out else co
+            wp = torch.zeros((cop, 3, 3, _pad64(ci)), dtype=w.dtype, device=w.device)
+            wp[:co, :, :, :ci] = w.permute(0, 2, 3, 1)
+            bp = torch.zeros((cop,), dtype=w.dtype, device=w.device)
+            bp[:co] = conv.bias.data
+            self._pk[name] = (wp.reshape(cop, -1).contiguous(), bp)
+        return self._pk[name]
+
+    def forward(self, cond_nchw: torch.Tensor) -> torch.Tensor:
+        """cond (B,3,H,W) in [0,1] -> NHWC (B,H/8,W/8,C0)."""
+        B, Cc, H, W = cond_nchw.shape
+        dt = self.conv_in.weight.dtype
+        x = torch.zeros((B, H, W, _pad64(Cc)), dtype=dt, device=cond_nchw.device)        # layout change of the input image
+        x[..., :Cc] = cond_nchw.permute(0, 2, 3, 1).to(dt)
+        w, b = self._padded("in", self.conv_in, True)
+        x = ops.conv2d(x, w, 3, bias=b, act=L.ACT_SILU)
+        for n, blk in enumerate(self.blocks):
+            w, b = self._padded(f"b{n}", blk, True)
+            x = ops.conv2d(x, w, 3, stride=blk.stride, bias=b, act=L.ACT_SILU)
+        w, b = self._padded("out", self.conv_out, False)
+        return ops.conv2d(x, w, 3, bias=b)
+
+
+class ControlNetModel(nn.Module):
+    def __init__(self, config: Optional[UNetConfig] = None, dtype: torch.dtype = torch.float16, device=None,
+                 conditioning_channels: int = 3):
+        super().__init__()
+        cfg = config or UNetConfig.sdxl()
+        self.config = cfg
+        self.config.global_pool_conditions = False
+        self._dtype = dtype
+        c0 = cfg.block_out_channels[0]
+        ted = c0 * 4
+        self.conv_in = Conv2d(cfg.in_channels, c0, 3, dtype=dtype, device=device)
+        self.time_embedding = TimestepEmbedding(c0, ted, dtype, device)
+        self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, ted, dtype, device)
+        self.controlnet_cond_embedding = ControlNetConditioningEmbedding(c0, conditioning_channels, dtype, device)
+        nb = len(cfg.block_out_channels)
+        self.down_blocks = nn.ModuleList()
+        cout = c0
+        chans = [c0]
+        for i, typ in enumerate(cfg.down_block_types):
+            cin, cout = cout, cfg.block_out_channels[i]
+            cls = CrossAttnDownBlock2D if typ == "CrossAttnDownBlock2D" else DownBlock2D
+            self.down_blocks.append(cls(cfg, i, cin, cout, typ == "CrossAttnDownBlock2D", i != nb - 1, dtype, device))
+            chans += [cout] * cfg.layers_per_block + ([cout] if i != nb - 1 else [])
+        self.mid_block = UNetMidBlock2DCrossAttn(cfg, dtype, device)
+        self.controlnet_down_blocks = nn.ModuleList([Conv2d(c, c, 1, dtype=dtype, device=device) for c in chans])
+        self.controlnet_mid_block = Conv2d(cfg.block_out_channels[-1], cfg.block_out_channels[-1], 1, dtype=dtype, device=device)
+        self._boundary = {}
+        self._cond_cache = None
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def invalidate_packed(self):
+        self._boundary = {}
+        self._cond_cache = None
+        for m in self.modules():
+            if m is not self and hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_packed()
+        return r
+
+    # the time/text embedding is the UNet's; reuse its implementation
+    from .unet import UNet2DConditionModel as _U
+    time_embed = _U.time_embed
+    del _U
+
+    def cond_features(self, controlnet_cond: torch.Tensor) -> torch.Tensor:
+        """Conditioning embedding, cached per conditioning tensor (it does not depend on the denoising step)."""
+        key = (controlnet_cond.data_ptr(), controlnet_cond._version, tuple(controlnet_cond.shape))
+        if self._cond_cache is None or self._cond_cache[0] != key:
+            self._cond_cache = (key, self.controlnet_cond_embedding(controlnet_cond), controlnet_cond)
+        return self._cond_cache[1]
+
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
+                conditioning_scale: float = 1.0, class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
+                cross_attention_kwargs=None, guess_mode: bool = False, return_dict: bool = False,
+                emb: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], torch.Tensor]:
+        if guess_mode:
+            raise L.OmgHipError("guess_mode is never set by OMG's flows (global_pool_conditions is False) and is not supported")
+        if not sample.is_cuda:
+            raise L.OmgHipError("ControlNetModel runs on the MI355X only (no CPU fallback)")
+        dt = self._dtype
+        B = sample.shape[0]
+        kw = dict(cross_attention_kwargs or {})
+        kw.pop("scale", None)
+        if emb is None:
+            emb = self.time_embed(timestep, B, added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"])
+        ehs = encoder_hidden_states
+        if ehs.dtype != dt or not ehs.is_contiguous():
+            ehs = ehs.to(dt).contiguous()
+        ctx = _Ctx(ops.silu(emb), ehs, B)
+        if not self._boundary:
+            self._boundary["in"] = ops.pack_conv_in_weight(self.conv_in.weight.data)
+        x_in = sample.contiguous()
+        if x_in.dtype not in (torch.float32, dt):
+            x_in = x_in.to(dt)
+        cond = self.cond_features(controlnet_cond)
+        if cond.shape[0] != B:
+            if B % cond.shape[0] != 0:
+                raise ValueError("controlnet_cond batch does not divide the sample batch")
+            cond = cond.repeat(B // cond.shape[0], 1, 1, 1)
+        h = ops.conv_in(x_in, self._boundary["in"], self.conv_in.bias, dt)
+        h = ops.add_(h, cond.contiguous())
+        skips: List[torch.Tensor] = [h]
+        for blk in self.down_blocks:
+            h = blk(h, ctx, kw, skips)
+        h = self.mid_block(h, ctx, kw)
+        down = []
+        for zc, s in zip(self.controlnet_down_blocks, skips):
+            y = ops.conv2d(s, zc.packed_weight(), 1, bias=zc.bias, out_scale=conditioning_scale)
+            down.append(y.permute(0, 3, 1, 2))                 # NCHW-shaped view of NHWC storage (channels_last)
+        mid = ops.conv2d(h, self.controlnet_mid_block.packed_weight(), 1, bias=self.controlnet_mid_block.bias,
+                         out_scale=conditioning_scale).permute(0, 3, 1, 2)
+        return down, mid

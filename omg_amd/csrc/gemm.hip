@@ -758,7 +758,8 @@ extern "C" int omg_conv2d(const omg_conv2d_args* a, void* stream) {
   p.K2 = 0; p.tile_groups = 1; p.rows_per_group = a->Hout * a->Wout;
   p.bias = (const char*)a->bias; p.group_bias = (const char*)a->group_bias; p.ldgb = a->ldgb;
   p.residual = (const char*)a->residual; p.ldr = a->Cout;
-  p.act = OMG_ACT_NONE; p.out_scale = a->out_scale; p.C = (char*)a->Y; p.ldc = a->Cout;
+  OMG_REQUIRE(a->act == OMG_ACT_NONE || a->act == OMG_ACT_SILU, "omg_conv2d: act");
+  p.act = a->act; p.out_scale = a->out_scale; p.C = (char*)a->Y; p.ldc = a->Cout;
   p.Hin = a->Hin; p.Win = a->Win; p.C1 = a->C1; p.C2 = a->C2; p.Hout = a->Hout; p.Wout = a->Wout;
   p.ksize = a->ksize; p.stride = a->stride; p.upsample = a->upsample;
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;

@@ -102,6 +102,18 @@ __global__ void silu_kernel(const T* x, T* y, long n) {
 }
 
 template <typename T>
+__global__ void add_inplace_kernel(char* y, const char* a, long nvec) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+    float f[8], g[8];
+    unpack8<T>(*(const u32x4*)(y + i * 16), f);
+    unpack8<T>(*(const u32x4*)(a + i * 16), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += g[e];
+    *(u32x4*)(y + i * 16) = pack8<T>(f);
+  }
+}
+
+template <typename T>
 __global__ void copy2d_kernel(const T* src, long lds_, T* dst, long ldd, long rows, long cols) {
   const long n = rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -252,6 +264,18 @@ extern "C" int omg_silu(int dtype, const void* x, void* y, int64_t n, void* stre
   if (dtype == OMG_F16) OMG_LAUNCH(silu_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const f16*)x, (f16*)y, (long)n);
   else OMG_LAUNCH(silu_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (bf16*)y, (long)n);
   return omg_check_launch("silu");
+}
+
+extern "C" int omg_add_inplace(int dtype, void* y, const void* a, int64_t n, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_add_inplace: dtype");
+  OMG_REQUIRE(y && a && n % 8 == 0, "omg_add_inplace: n % 8");
+  if (n == 0) return OMG_OK;
+  const long nvec = n / 8;
+  long blocks = (nvec + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMG_F16) OMG_LAUNCH(add_inplace_kernel<f16>, dim3(blocks), dim3(256), 0, s, (char*)y, (const char*)a, nvec);
+  else OMG_LAUNCH(add_inplace_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (char*)y, (const char*)a, nvec);
+  return omg_check_launch("add_inplace");
 }
 
 extern "C" int omg_copy2d(int dtype, const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {

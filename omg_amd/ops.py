@@ -163,7 +163,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
 def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, upsample: bool = False,
            x2: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
            group_bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           out_scale: float = 1.0) -> torch.Tensor:
+           out_scale: float = 1.0, act: int = L.ACT_NONE) -> torch.Tensor:
     """NHWC implicit-GEMM conv; ``w`` is ``[Cout, ksize*ksize*(C1+C2)]`` (see pack_conv_weight)."""
     _dev(x1)
     B, Hin, Win, C1 = x1.shape
@@ -191,6 +191,7 @@ def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, up
         assert residual.is_contiguous() and residual.shape == y.shape
         a.residual = residual.data_ptr()
     a.out_scale = out_scale
+    a.act = act
     a.Y = y.data_ptr()
     if _PROF is not None:
         t0 = _PROF.begin()
@@ -368,6 +369,14 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     assert x.is_contiguous()
     y = torch.empty_like(x)
     L.check(L.lib().omg_silu(_dt(x), x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "omg_silu")
+    return y
+
+
+def add_(y: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    """y += a (same shape, contiguous)."""
+    _dev(y)
+    assert y.is_contiguous() and a.is_contiguous() and y.shape == a.shape and y.dtype == a.dtype
+    L.check(L.lib().omg_add_inplace(_dt(y), y.data_ptr(), a.data_ptr(), y.numel(), _stream()), "omg_add_inplace")
     return y
 
 

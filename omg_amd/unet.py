@@ -374,6 +374,15 @@ class UNet2DConditionModel(nn.Module):
             self._boundary["out"] = self.conv_out.weight.data.permute(0, 2, 3, 1).contiguous()
         return self._boundary
 
+    @staticmethod
+    def _nhwc(r: torch.Tensor, dt) -> torch.Tensor:
+        """NCHW-shaped residual -> contiguous NHWC in `dt` (free when it already is a channels_last view, as the
+        residuals of omg_amd.controlnet are)."""
+        v = r.permute(0, 2, 3, 1)
+        if v.dtype != dt:
+            v = v.to(dt)
+        return v if v.is_contiguous() else v.contiguous()
+
     def time_embed(self, timestep, B: int, text_embeds: torch.Tensor, time_ids: torch.Tensor) -> torch.Tensor:
         """emb = time_embedding(sincos(t)) + add_embedding([text_embeds | sincos(time_ids)])  -> (B, 4*C0)."""
         cfg = self.config
@@ -427,10 +436,14 @@ class UNet2DConditionModel(nn.Module):
         for blk in self.down_blocks:
             h = blk(h, ctx, kw, skips)
         if down_block_additional_residuals is not None:
-            skips = [s + r.permute(0, 2, 3, 1).to(dt) for s, r in zip(skips, down_block_additional_residuals)]
+            if len(down_block_additional_residuals) != len(skips):
+                raise ValueError(f"expected {len(skips)} down-block residuals, got {len(down_block_additional_residuals)}")
+            skips[-1] = skips[-1].clone()                 # the last skip aliases `h`, which enters the mid block UN-modified
+            for s_, r in zip(skips, down_block_additional_residuals):
+                ops.add_(s_, self._nhwc(r, dt))           # `down_block_res_sample + residual` for every skip tensor
         h = self.mid_block(h, ctx, kw)
         if mid_block_additional_residual is not None:
-            h = h + mid_block_additional_residual.permute(0, 2, 3, 1).to(dt)
+            ops.add_(h, self._nhwc(mid_block_additional_residual, dt))
         for blk in self.up_blocks:
             h = blk(h, ctx, kw, skips)
         h = self.conv_norm_out(h, silu=True)

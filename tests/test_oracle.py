@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import controller as oc
+from oracle import controlnet as ocn
 from oracle import ip_adapter as oip
 from oracle import pipeline as opipe
 from oracle import schedulers as osched
@@ -162,3 +163,14 @@ def test_schedulers_basic_properties():
     eu = osched.EulerDiscrete(50)
     assert np.all(np.diff(eu.sigmas) < 0) and eu.sigmas[-1] == 0
     assert abs(eu.init_noise_sigma - (eu.sigmas[0] ** 2 + 1) ** 0.5) < 1e-12
+
+
+def test_controlnet_topology_parameter_count():
+    n = 0
+    for shp in ocn.param_shapes(ounet.UNetConfig.sdxl()).values():
+        k = 1
+        for d in shp:
+            k *= d
+        n += k
+    assert n == 1_251_014_160        # SDXL ControlNet: encoder copy of the UNet + conditioning embedding + 10 zero convs
+    assert len([k for k in ocn.param_shapes(ounet.UNetConfig.sdxl()) if k.startswith("controlnet_down_blocks.") and k.endswith(".weight")]) == 9
