@@ -59,6 +59,10 @@ class Attention(nn.Module):
         self._qkv_slots = None    # merged-LoRA mode: [1+slots, 3*inner, C]
         self._kv_slots = None
         self._kv_cache = {}       # key -> (K, V^T, ctx) projections of constant encoder_hidden_states
+        # IP-Adapter branch (omg_amd.ip_adapter.IPAdapter): fused [to_k_ip ; to_v_ip] weight, scale, token count
+        self.ip_kv_weight: Optional[torch.Tensor] = None
+        self.ip_scale, self.ip_tokens = 1.0, 16
+        self._ip_cache = None
 
     # ---- diffusers API
     def set_processor(self, processor) -> None:
@@ -175,6 +179,22 @@ class Attention(nn.Module):
         return k, vt
 
 
+def _ip_branch(attn: Attention, q: torch.Tensor, o: torch.Tensor, ip_ctx: torch.Tensor, row0: int) -> None:
+    """o[row0:] += ip_scale * softmax(q[row0:] K_ip^T) V_ip   (src/ip_adapter/attention_processor.py:391-409)."""
+    stamp = (ip_ctx.data_ptr(), ip_ctx._version, tuple(ip_ctx.shape))
+    c = attn._ip_cache
+    if c is None or c[0] != stamp:
+        Bc, Ni, Cx = ip_ctx.shape
+        kv_out = c[3] if (c is not None and tuple(c[4]) == tuple(ip_ctx.shape)) else None
+        vt_out = c[2] if kv_out is not None else None
+        kv = ops.gemm(ip_ctx.reshape(Bc * Ni, Cx), attn.ip_kv_weight, out=kv_out)
+        kv3 = kv.view(Bc, Ni, 2 * attn.inner_dim)
+        vt = ops.transpose_v(kv3[:, :, attn.inner_dim:], attn.heads, out=vt_out)
+        c = (stamp, kv3[:, :, :attn.inner_dim], vt, kv, tuple(ip_ctx.shape), ip_ctx)
+        attn._ip_cache = c
+    ops.attention(q[row0:], c[1], c[2], attn.heads, attn.scale, out=o[row0:], accumulate=True, out_scale=attn.ip_scale)
+
+
 def _to_tokens(attn, hidden_states):
     if hidden_states.dim() == 4:
         raise L.OmgHipError("4-D (NCHW) hidden_states are not produced by the SDXL transformer blocks; pass (B, N, C)")
@@ -206,7 +226,11 @@ class FusedAttnProcessor:
         main_b = cross_attention_kwargs.pop("omg_main_batch", None)       # p2p batch per request [unc0,unc1,cond0,cond1]
         n_img = cross_attention_kwargs.pop("omg_images", 1)               # requests batched in lock-step
         src = None if bypass else self._qk_src(attn, is_cross, N, B, x.device, main_b, n_img)
+        ip_ctx = cross_attention_kwargs.pop("omg_ip_tokens", None)         # (rows, 16, Cx) image-prompt tokens of the rows
+        ip_row0 = cross_attention_kwargs.pop("omg_ip_rows", 0)             #   [ip_row0:] of the batch (InstantID concept samples)
         o = ops.attention(q, k, vt, attn.heads, attn.scale, qk_src=src)
+        if is_cross and ip_ctx is not None and attn.ip_kv_weight is not None:
+            _ip_branch(attn, q, o, ip_ctx, ip_row0)
         out = attn.to_out[0](o, residual=residual)
         return out
 

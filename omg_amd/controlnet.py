@@ -23,6 +23,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
+from .attention import Attention
 from .modules import Conv2d
 from .unet import (CrossAttnDownBlock2D, DownBlock2D, TimestepEmbedding, UNetConfig, UNetMidBlock2DCrossAttn, _Ctx)
 
@@ -132,9 +133,19 @@ class ControlNetModel(nn.Module):
     def cond_features(self, controlnet_cond: torch.Tensor) -> torch.Tensor:
         """Conditioning embedding, cached per conditioning tensor (it does not depend on the denoising step)."""
         key = (controlnet_cond.data_ptr(), controlnet_cond._version, tuple(controlnet_cond.shape))
-        if self._cond_cache is None or self._cond_cache[0] != key:
-            self._cond_cache = (key, self.controlnet_cond_embedding(controlnet_cond), controlnet_cond)
+        c = self._cond_cache
+        if c is None or c[0] != key:
+            feat = self.controlnet_cond_embedding(controlnet_cond)
+            if c is not None and c[1].shape == feat.shape:
+                c[1].copy_(feat)                # keep the pointer stable for captured step graphs
+                feat = c[1]
+            self._cond_cache = (key, feat, controlnet_cond)
         return self._cond_cache[1]
+
+    def refresh_cross_kv(self, ctx: torch.Tensor) -> None:
+        for m in self.modules():
+            if isinstance(m, Attention) and m.is_cross:
+                m.project_cross(ctx)
 
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, controlnet_cond: torch.Tensor,
                 conditioning_scale: float = 1.0, class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
@@ -163,7 +174,7 @@ class ControlNetModel(nn.Module):
         if cond.shape[0] != B:
             if B % cond.shape[0] != 0:
                 raise ValueError("controlnet_cond batch does not divide the sample batch")
-            cond = cond.repeat(B // cond.shape[0], 1, 1, 1)
+            cond = cond.repeat_interleave(B // cond.shape[0], dim=0)      # each conditioning image covers a block of consecutive rows
         h = ops.conv_in(x_in, self._boundary["in"], self.conv_in.bias, dt)
         h = ops.add_(h, cond.contiguous())
         skips: List[torch.Tensor] = [h]

@@ -1,0 +1,65 @@
+"""IP-Adapter (InstantID) weights for the concept UNet — rows A12 / config 3 of SURVEY.md §8.
+
+Mirrors ``StableDiffusionXLInstantIDPipeline.set_ip_adapter`` (/root/reference src/pipelines/instantid_single_pieline.py:186-213):
+every cross-attention (attn2) of the UNet gets ``to_k_ip`` / ``to_v_ip`` Linear(cross_attention_dim -> hidden) and a scale;
+the checkpoint's ``ip_adapter`` state dict is keyed by the layer's index in ``unet.attn_processors`` order
+(``"{idx}.to_k_ip.weight"``), exactly as ``torch.nn.ModuleList(unet.attn_processors.values()).load_state_dict`` expects.
+
+The arithmetic (src/ip_adapter/attention_processor.py:383-409) — ``SDPA(q, K_text, V_text) + scale * SDPA(q, K_ip, V_ip)`` — runs as
+a second, accumulating call of the flash kernel over the 16 image-prompt tokens (``omg_attn_fwd`` ``accumulate``).  Because the
+concept samples share the batched forward with the main samples (which have no ip tokens), the weights hang on the ``Attention``
+modules and the processors apply them to the row range named by ``omg_ip_rows``.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .attention import Attention
+
+
+class IPAdapter:
+    def __init__(self, unet, num_tokens: int = 16, scale: float = 0.5):
+        self.unet, self.num_tokens, self.scale = unet, num_tokens, scale
+        self.layers = []            # (index in attn_processors order, module name, Attention)
+        for idx, (name, m) in enumerate(unet.attentions()):
+            if m.is_cross:
+                self.layers.append((idx, name, m))
+
+    def _install(self, m: Attention, wk: torch.Tensor, wv: torch.Tensor) -> None:
+        dev, dt = self.unet.device, self.unet.dtype
+        m.ip_kv_weight = torch.cat([wk, wv], dim=0).to(device=dev, dtype=dt).contiguous()      # [2C, Cx]
+        m.ip_scale, m.ip_tokens = self.scale, self.num_tokens
+        m._ip_cache = None
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        if "ip_adapter" in sd:
+            sd = sd["ip_adapter"]
+        for idx, name, m in self.layers:
+            self._install(m, sd[f"{idx}.to_k_ip.weight"], sd[f"{idx}.to_v_ip.weight"])
+
+    def load_named(self, weights: Dict[str, tuple]) -> None:
+        """weights[attn2 module name] = (to_k_ip, to_v_ip)."""
+        for idx, name, m in self.layers:
+            self._install(m, *weights[name])
+
+    def init_synthetic_(self, seed: int = 0) -> "IPAdapter":
+        g = torch.Generator(device=self.unet.device).manual_seed(seed)
+        cx = self.unet.config.cross_attention_dim
+        for idx, name, m in self.layers:
+            c = m.inner_dim
+            wk = torch.randn(c, cx, generator=g, device=self.unet.device) * cx ** -0.5
+            wv = torch.randn(c, cx, generator=g, device=self.unet.device) * cx ** -0.5
+            self._install(m, wk, wv)
+        return self
+
+    def set_scale(self, scale: float) -> None:
+        self.scale = scale
+        for _, _, m in self.layers:
+            m.ip_scale = scale
+
+    def remove(self) -> None:
+        for _, _, m in self.layers:
+            m.ip_kv_weight = None

@@ -174,8 +174,9 @@ class LoraMultiConceptPipeline:
                  styleL: Optional[bool] = None, region_prompt_embeds: Optional[Sequence[Tuple[torch.Tensor, ...]]] = None,
                  use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START,
                  lora_mode: str = "merged", **kwargs):
-        if image is not None:
-            raise L.OmgHipError("ControlNet conditioning (image=) is a 'next' row of SURVEY §8f (N2) and is not implemented")
+        controlnet = kwargs.pop("controlnet", getattr(self, "controlnet", None))
+        if image is not None and controlnet is None:
+            raise L.OmgHipError("image= needs a ControlNet: pass controlnet=omg_amd.controlnet.ControlNetModel(...)")
         if eta != 0.0:
             raise L.OmgHipError("eta != 0 (stochastic DDIM) is not used by OMG and is not supported")
         lora_list = list(lora_list or [])
@@ -200,7 +201,8 @@ class LoraMultiConceptPipeline:
                                  original_size=original_size, crops_coords_top_left=crops_coords_top_left, target_size=target_size,
                                  controller=controller, concept_models=concept_models, stage=stage, lora_list=lora_list,
                                  styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
-                                 lora_mode=lora_mode)[0]
+                                 lora_mode=lora_mode, controlnet=controlnet if image is not None else None, controlnet_image=image,
+                                 controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0))[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         if output_type == "latent":
@@ -220,11 +222,19 @@ class LoraMultiConceptPipeline:
                       original_size=None, crops_coords_top_left=(0, 0), target_size=None, controller=None,
                       concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None,
                       lora_list: Optional[Sequence[str]] = None, styleL: Optional[bool] = None, use_graph: bool = False,
-                      trajectory: Optional[list] = None, fusion_start: int = FUSION_START, lora_mode: str = "merged") -> torch.Tensor:
+                      trajectory: Optional[list] = None, fusion_start: int = FUSION_START, lora_mode: str = "merged",
+                      controlnet=None, controlnet_image: Optional[torch.Tensor] = None, controlnet_conditioning_scale: float = 1.0,
+                      identitynet=None, identitynet_conditioning_scale: float = 1.0) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
-        All requests must agree on which concepts have a mask."""
+        All requests must agree on which concepts have a mask.
+
+        ``controlnet`` + ``controlnet_image`` (1|n,3,H,W in [0,1]): ControlNet on the MAIN pass of every step
+        (lora_pipeline.py:519-536; ``controlnet2``/``t2i_image`` of instantid_pipeline.py:574-592).
+        ``identitynet`` (InstantID, instantid_pipeline.py:638-674): ControlNet on the CONCEPT pass fed with the face tokens and
+        the request's ``kps_image`` (1,3,H,W); requests then also carry ``region_image_embeds`` = [(2,16,Cx) [zero-id, id]] * K and
+        the UNet must have an :class:`omg_amd.ip_adapter.IPAdapter` installed."""
         dev, dt = self.unet.device, self.unet.dtype
         n = len(requests)
         height = height or self.unet.config.sample_size * self.vae_scale_factor
@@ -238,7 +248,7 @@ class LoraMultiConceptPipeline:
         target_size = target_size or (height, width)
         Cl = self.unet.config.in_channels
         # ---- per-request tensors
-        lats, ehs_l, text_l, masks_l, cehs_l, ctext_l = [], [], [], [], [], []
+        lats, ehs_l, text_l, masks_l, cehs_l, ctext_l, ip_l, kps_l = [], [], [], [], [], [], [], []
         active = None
         for r in requests:
             pe, ne = r["prompt_embeds"], r["negative_prompt_embeds"]
@@ -266,6 +276,12 @@ class LoraMultiConceptPipeline:
             if act:
                 cehs_l.append(torch.cat([torch.cat([rpe[c][0], rpe[c][1]], dim=0) for c in act], dim=0).to(device=dev, dtype=dt))
                 ctext_l.append(torch.cat([torch.cat([rpe[c][2], rpe[c][3]], dim=0) for c in act], dim=0).to(device=dev, dtype=dt))
+                if identitynet is not None:
+                    rie = r.get("region_image_embeds")
+                    if rie is None or len(rie) != K or r.get("kps_image") is None:
+                        raise ValueError("identitynet needs region_image_embeds [(2,16,Cx)] * K and kps_image per request")
+                    ip_l.append(torch.cat([rie[c] for c in act], dim=0).to(device=dev, dtype=dt))
+                    kps_l.append(r["kps_image"].to(device=dev, dtype=torch.float32))
         Ka = len(active)
         Hl, Wl = lats[0].shape[2:]
         fuse_possible = stage == 2 and Ka > 0 and S > fusion_start + 1
@@ -290,14 +306,21 @@ class LoraMultiConceptPipeline:
             c_ehs = torch.cat(cehs_l, dim=0).contiguous()                                           # (2Ka*n, 77, Cx)
             emb_conc = self._all_step_embeddings(ts, torch.cat(ctext_l, dim=0),
                                                  self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev))
-        batched = fuse_possible and concept_models.bank is not None and concept_models.bank.mode == "merged"
+        batched = fuse_possible and (concept_models.bank is None or concept_models.bank.mode == "merged")
         if use_graph and fuse_possible and not batched:
             raise L.OmgHipError("use_graph needs lora_mode='merged' (segment-mode K/V projections are not pointer-stable)")
+        use_cn = controlnet is not None
+        use_idn = identitynet is not None and fuse_possible
+        if use_cn and controlnet_image is None:
+            raise ValueError("controlnet needs controlnet_image")
+        if use_idn and not batched:
+            raise L.OmgHipError("identitynet runs in the batched (merged / no-LoRA) mode only")
         mshape = tuple(masks_l[0][active[0]].shape) if active else (0, 0)
         D = emb_main.shape[-1]
         # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
         key = (n, S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
-               str(dt), batched, bool(styleL), tuple(lora_list), mshape, tuple(ehs.shape), id(controller))
+               str(dt), batched, bool(styleL), tuple(lora_list), mshape, tuple(ehs.shape), id(controller), id(controlnet), id(identitynet),
+               float(controlnet_conditioning_scale), float(identitynet_conditioning_scale))
         eng = self._engines.get(key)
         if eng is None:
             eng = SimpleNamespace(graphs={}, warmed=set(), pool=None, coef=None)
@@ -317,6 +340,15 @@ class LoraMultiConceptPipeline:
                 eng.ehs_all = torch.empty((nb,) + tuple(ehs.shape[1:]), dtype=dt, device=dev)
                 eng.emb_all = torch.empty((S, nb, D), dtype=dt, device=dev)
                 eng.emb_cur_all = torch.empty((nb, D), dtype=dt, device=dev)
+            if use_cn:
+                eng.cn_image = torch.empty((controlnet_image.shape[0], 3, height, width), dtype=torch.float32, device=dev)
+                eng.cn_emb = torch.empty((S, nm, D), dtype=dt, device=dev)
+                eng.cn_emb_cur = torch.empty((nm, D), dtype=dt, device=dev)
+            if use_idn:
+                eng.ip_all = torch.empty((ncn,) + tuple(ip_l[0].shape[1:]), dtype=dt, device=dev)
+                eng.kps_all = torch.empty((n, 3, height, width), dtype=torch.float32, device=dev)
+                eng.idn_emb = torch.empty((S, ncn, D), dtype=dt, device=dev)
+                eng.idn_emb_cur = torch.empty((ncn, D), dtype=dt, device=dev)
             if len(self._engines) >= 4:
                 self._engines.pop(next(iter(self._engines)))
             self._engines[key] = eng
@@ -347,12 +379,30 @@ class LoraMultiConceptPipeline:
             eng.ehs_all[nm:].copy_(c_ehs)
             eng.emb_all[:, :nm].copy_(emb_main)
             eng.emb_all[:, nm:].copy_(emb_conc)
-            state_all = concept_models.lora_state([0] * nm + [s + 1 for s in slots], merged=True)
+            state_all = concept_models.lora_state([0] * nm + [s + 1 for s in slots], merged=True) if concept_models.bank is not None else None
+        tids_m = self._add_time_ids(original_size, crops_coords_top_left, target_size, nm, dev)
+        if use_cn:
+            eng.cn_image.copy_(controlnet_image.to(device=dev, dtype=torch.float32))
+            t_all = ts.reshape(S, 1).expand(S, nm).reshape(-1).contiguous()
+            eng.cn_emb.copy_(controlnet.time_embed(t_all, S * nm, torch.cat(text_l, dim=0).repeat(S, 1), tids_m.repeat(S, 1)).view(S, nm, D))
+        if use_idn:
+            eng.ip_all.copy_(torch.cat(ip_l, dim=0))
+            eng.kps_all.copy_(torch.cat(kps_l, dim=0))
+            t_all = ts.reshape(S, 1).expand(S, ncn).reshape(-1).contiguous()
+            tids_c = self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev)
+            eng.idn_emb.copy_(identitynet.time_embed(t_all, S * ncn, torch.cat(ctext_l, dim=0).repeat(S, 1), tids_c.repeat(S, 1)).view(S, ncn, D))
         if use_graph:
-            # cached cross-attention K/V must be refreshed eagerly: replayed graphs read the stored projections
+            # cached cross-attention K/V (and ControlNet conditioning features) must be refreshed eagerly:
+            # replayed graphs read the stored tensors
             self.unet.refresh_cross_kv(eng.ehs, None)
             if batched:
                 self.unet.refresh_cross_kv(eng.ehs_all, state_all)
+            if use_cn:
+                controlnet.refresh_cross_kv(eng.ehs)
+                controlnet.cond_features(eng.cn_image)
+            if use_idn:
+                identitynet.refresh_cross_kv(eng.ip_all)
+                identitynet.cond_features(eng.kps_all)
 
         def region_rows(j):
             return nm + 2 * Ka * j
@@ -364,17 +414,34 @@ class LoraMultiConceptPipeline:
 
         def step_body(fused: bool):
             """One denoising iteration; every per-step quantity is selected by the DEVICE step counter."""
+            kw = dict(main_kw)
+            residuals = []
+            if use_cn:                                    # ControlNet on the main samples (lora_pipeline.py:519-536)
+                ops.gather_step(eng.cn_emb, step_idx, eng.cn_emb_cur)
+                d_, m_ = controlnet(xin[:nm], None, encoder_hidden_states=eng.ehs, controlnet_cond=eng.cn_image,
+                                    conditioning_scale=controlnet_conditioning_scale, emb=eng.cn_emb_cur)
+                residuals.append((0, nm, d_, m_))
             if fused and batched:
                 fill_region_inputs()
+                if use_idn:                               # IdentityNet on the concept samples (instantid_pipeline.py:638-648)
+                    ops.gather_step(eng.idn_emb, step_idx, eng.idn_emb_cur)
+                    d_, m_ = identitynet(xin[nm:], None, encoder_hidden_states=eng.ip_all, controlnet_cond=eng.kps_all,
+                                         conditioning_scale=identitynet_conditioning_scale, emb=eng.idn_emb_cur)
+                    residuals.append((nm, nb, d_, m_))
+                    kw["omg_ip_tokens"], kw["omg_ip_rows"] = eng.ip_all, nm
+                if residuals:
+                    kw["omg_residuals"] = residuals
                 ops.gather_step(eng.emb_all, step_idx, eng.emb_cur_all)
-                self.unet.set_lora_state(state_all)
+                self.unet.set_lora_state(state_all if concept_models.bank is not None else None)
                 try:
-                    self.unet(xin, None, encoder_hidden_states=eng.ehs_all, cross_attention_kwargs=main_kw, emb=eng.emb_cur_all, out=nout)
+                    self.unet(xin, None, encoder_hidden_states=eng.ehs_all, cross_attention_kwargs=kw, emb=eng.emb_cur_all, out=nout)
                 finally:
                     self.unet.set_lora_state(None)
             else:
+                if residuals:
+                    kw["omg_residuals"] = residuals
                 ops.gather_step(eng.emb_main, step_idx, eng.emb_cur_main)
-                self.unet(xin[:nm], None, encoder_hidden_states=eng.ehs, cross_attention_kwargs=main_kw, emb=eng.emb_cur_main, out=nout[:nm])
+                self.unet(xin[:nm], None, encoder_hidden_states=eng.ehs, cross_attention_kwargs=kw, emb=eng.emb_cur_main, out=nout[:nm])
                 if fused:
                     fill_region_inputs()
                     ops.gather_step(eng.emb_conc, step_idx, eng.emb_cur_conc)
@@ -421,3 +488,52 @@ class LoraMultiConceptPipeline:
             if trajectory is not None:
                 trajectory.append(lat.clone().view(n, 2, Cl, Hl, Wl))
         return lat.clone().view(n, 2, Cl, Hl, Wl)
+
+
+class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
+    """OMG + InstantID (/root/reference src/pipelines/instantid_pipeline.py:157-768, BASELINE config 3) on the same step engine.
+
+    Reference roles -> here: ``self.controlnet`` (IdentityNet, applied to every CONCEPT pass with the face tokens as context and the
+    key-point image as conditioning, :638-648) = ``identitynet``; ``self.controlnet2`` + ``t2i_image`` (optional pose/depth ControlNet on the
+    MAIN pass, :574-616) = ``controlnet2``; the concept UNet's IP-Adapter processors (instantid_single_pieline.py:186-213) = an
+    :class:`omg_amd.ip_adapter.IPAdapter` installed on the shared UNet.  Face detection / ArcFace embedding (``face_app``) and the
+    Resampler that turns a 512-d embedding into 16 tokens run once per image outside the hot path: pass the
+    resulting tokens as ``region_image_embeds`` = [(2, 16, Cx) = [tokens of the zero embedding, tokens of the identity]] per concept."""
+
+    def __init__(self, unet, identitynet, scheduler=None, controlnet2=None, **kw):
+        super().__init__(unet, scheduler, **kw)
+        self.controlnet = identitynet
+        self.controlnet2 = controlnet2
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None,
+                 image: Optional[torch.Tensor] = None, t2i_image: Optional[torch.Tensor] = None, height=None, width=None,
+                 num_inference_steps: int = 50, guidance_scale: float = 5.0, generator=None, latents=None,
+                 controlnet_conditioning_scale: float = 1.0, t2i_controlnet_conditioning_scale: float = 1.0, controller=None,
+                 concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None, region_masks=None,
+                 region_prompt_embeds=None, region_image_embeds=None, output_type: str = "latent", return_dict: bool = True,
+                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, **kwargs):
+        if prompt_embeds is None:
+            raise L.OmgHipError("pass prompt_embeds=/pooled_prompt_embeds= (text encoders are outside this package's scope)")
+        K = len(region_prompt_embeds or [])
+        # stage 1 is called with image=None: no IdentityNet (instantid_pipeline.py:393, :426-428)
+        use_idn = stage == 2 and image is not None
+        req = dict(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+                   negative_pooled_prompt_embeds=negative_pooled_prompt_embeds, region_prompt_embeds=region_prompt_embeds or [],
+                   region_masks=region_masks, latents=latents, generator=generator,
+                   region_image_embeds=region_image_embeds if use_idn else None, kps_image=image if use_idn else None)
+        traj_many = [] if trajectory is not None else None
+        lat = self.generate_many([req], height=height, width=width, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                                 controller=controller, concept_models=concept_models or ConceptModels(self.unet, None), stage=stage,
+                                 lora_list=[f"id{c}" for c in range(K)], styleL=False, use_graph=use_graph, trajectory=traj_many,
+                                 fusion_start=fusion_start, identitynet=self.controlnet if use_idn else None,
+                                 identitynet_conditioning_scale=controlnet_conditioning_scale,
+                                 controlnet=self.controlnet2 if t2i_image is not None else None, controlnet_image=t2i_image,
+                                 controlnet_conditioning_scale=t2i_controlnet_conditioning_scale)[0]
+        if trajectory is not None:
+            trajectory.extend(t[0] for t in traj_many)
+        if output_type != "latent":
+            if self.vae_decode is None:
+                raise L.OmgHipError("VAE decode is a 'next' row (SURVEY §8f N1): use output_type='latent' or pass vae_decode=")
+            lat = self.vae_decode(lat)
+        return StableDiffusionXLPipelineOutput(images=lat) if return_dict else (lat,)

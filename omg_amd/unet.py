@@ -422,6 +422,7 @@ class UNet2DConditionModel(nn.Module):
         dt = self._dtype
         kw = dict(cross_attention_kwargs or {})
         kw.pop("scale", None)          # LoRA scale is baked into the LoRA bank (omg_amd.lora)
+        row_residuals = kw.pop("omg_residuals", None)     # [(row0, row1, down[9], mid)]: ControlNet residuals for a row range
         if emb is None:
             if added_cond_kwargs is None:
                 raise L.OmgHipError("added_cond_kwargs={'text_embeds','time_ids'} is required (addition_embed_type='text_time')")
@@ -441,9 +442,17 @@ class UNet2DConditionModel(nn.Module):
             skips[-1] = skips[-1].clone()                 # the last skip aliases `h`, which enters the mid block UN-modified
             for s_, r in zip(skips, down_block_additional_residuals):
                 ops.add_(s_, self._nhwc(r, dt))           # `down_block_res_sample + residual` for every skip tensor
+        if row_residuals:
+            skips[-1] = skips[-1].clone() if down_block_additional_residuals is None else skips[-1]
+            for r0, r1, down, _ in row_residuals:
+                for s_, r in zip(skips, down):
+                    ops.add_(s_[r0:r1], self._nhwc(r, dt))
         h = self.mid_block(h, ctx, kw)
         if mid_block_additional_residual is not None:
             ops.add_(h, self._nhwc(mid_block_additional_residual, dt))
+        if row_residuals:
+            for r0, r1, _, mid in row_residuals:
+                ops.add_(h[r0:r1], self._nhwc(mid, dt))
         for blk in self.up_blocks:
             h = blk(h, ctx, kw, skips)
         h = self.conv_norm_out(h, silu=True)

@@ -40,3 +40,21 @@ def ip_cross_attention(hidden, ctx, to_q, to_k, to_v, to_out_w, to_out_b, to_k_i
 def self_attention(hidden, to_q, to_k, to_v, to_out_w, to_out_b, heads):
     o = _sdpa(F.linear(hidden, to_q), F.linear(hidden, to_k), F.linear(hidden, to_v), heads)
     return F.linear(o, to_out_w, to_out_b)
+
+
+def make_ip_attn_fn(ip_weights, scale: float, num_tokens: int, base_attn_fn=None):
+    """attn_fn for oracle.unet.unet_forward implementing the concept UNet of InstantID: self-attention is plain SDPA,
+    cross-attention is IPAttnProcessor2_0 (the last ``num_tokens`` context rows are image-prompt tokens).
+    ``ip_weights[attn2 module name] = (to_k_ip [C, Cx], to_v_ip [C, Cx])``."""
+    from . import unet as ou
+
+    def fn(name, heads, q, k, v, is_cross):
+        return (base_attn_fn or ou.plain_attention)(name, heads, q, k, v, is_cross)
+
+    def cross(sd, name, heads, x, ctx):
+        wk, wv = ip_weights[name]
+        return ip_cross_attention(x, ctx, sd[name + ".to_q.weight"], sd[name + ".to_k.weight"], sd[name + ".to_v.weight"],
+                                  sd[name + ".to_out.0.weight"], sd[name + ".to_out.0.bias"], wk, wv, heads, scale, num_tokens)
+
+    fn.cross_override = cross
+    return fn

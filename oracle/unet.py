@@ -237,6 +237,8 @@ def plain_attention(name: str, heads: int, q: Tensor, k: Tensor, v: Tensor, is_c
 
 def attention(sd, name, heads, x, ctx, attn_fn: AttnFn, lora=None):
     is_cross = ctx is not None
+    if is_cross and getattr(attn_fn, "cross_override", None) is not None:
+        return attn_fn.cross_override(sd, name, heads, x, ctx)        # e.g. IP-Adapter: own K/V projections for the ip tokens
     src = ctx if is_cross else x
 
     def proj(n, inp):
