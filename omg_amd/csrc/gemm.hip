@@ -171,8 +171,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   const int tiles_per_group = p.tiles_m * p.tiles_n;
   const int grp = bid / tiles_per_group;
   const int t_in = bid - grp * tiles_per_group;
-  const int tm = t_in % p.tiles_m;
-  const int tn = t_in / p.tiles_m;
+  // grouped ordering: 8 M-tiles x all N-tiles per group, M fastest inside the group, so that the ~32 consecutive
+  // tiles an XCD receives touch ~8 A panels + <= 4..5 W panels instead of 32 + 1 (tall-skinny GEMMs re-read A per N tile)
+  int tm, tn;
+  {
+    const int per_group = 8 * p.tiles_n;
+    const int gid = t_in / per_group;
+    const int first_m = gid * 8;
+    const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int r = t_in - gid * per_group;
+    tm = first_m + (r % gsz);
+    tn = r / gsz;
+  }
   const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
   const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
   const int m0 = m_base + tm * BM;
@@ -420,7 +430,7 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, in
   }
 }
 
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST3>
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST3, bool STAG>
 __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
   constexpr int NW = WM_ * WN_;
   constexpr int MT = BM_ / WM_ / 32;             // 32-row MFMA tiles per wave (2 or 4)
@@ -449,8 +459,18 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
   const int tiles_per_group = p.tiles_m * p.tiles_n;
   const int grp = bid / tiles_per_group;
   const int t_in = bid - grp * tiles_per_group;
-  const int tm = t_in % p.tiles_m;
-  const int tn = t_in / p.tiles_m;
+  // grouped ordering: 8 M-tiles x all N-tiles per group, M fastest inside the group, so that the ~32 consecutive
+  // tiles an XCD receives touch ~8 A panels + <= 4..5 W panels instead of 32 + 1 (tall-skinny GEMMs re-read A per N tile)
+  int tm, tn;
+  {
+    const int per_group = 8 * p.tiles_n;
+    const int gid = t_in / per_group;
+    const int first_m = gid * 8;
+    const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int r = t_in - gid * per_group;
+    tm = first_m + (r % gsz);
+    tn = r / gsz;
+  }
   const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
   const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
   const int m0 = m_base + tm * BM_;
@@ -584,32 +604,74 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
   for (int s = 0; s < NST3 - 1; ++s)
     if (s < nk) issue(s);
 
-  // Main loop: counted wait for stage kt, ONE barrier, DMA three stages ahead, then 2 k-steps of MFMAs.
-  // (A variant with the barrier between the two k-steps and fragment reads issued one k-step ahead measured
-  //  2-5 % slower on MI355X: the compiler already overlaps the second k-step's ds_reads with the first's MFMAs.)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int ahead = nk - 1 - kt;         // later stages whose DMA may stay in flight: min(ahead, NST3 - 2)
-    if (!(p.dbg & 2)) {
+  if constexpr (STAG) {
+    // Staggered main loop (8-wave configurations).  Waves w and w+4 share a SIMD; all 8 meet at ONE barrier per stage,
+    // but the upper four run half a stage behind: after barrier k the lower group ISSUES (DMA for stage k+3, the 12
+    // fragment reads of stage k) and then computes stage k, while the upper group first computes stage k-1 from the
+    // fragments it read last time and only then issues/reads.  On every SIMD one wave is therefore in its 16-MFMA
+    // section while its partner is in its load section, instead of both hitting the LDS/DMA path and then the matrix
+    // pipe together (the lock-step structure measured 43 % MFMA-busy with 37 % of wave time in s_waitcnt/barrier).
+    // Hazards: stage k's buffer is read by both groups between barrier k and k+1; the DMA issued after barrier k
+    // targets buffer (k+3)%4 = (k-1)%4, last read before barrier k by both groups.
+    const bool late = w >= NW / 2;
+    V8 af[2][MT], bf[2][NT];
+    auto mma = [&]() {
+      if (p.dbg & 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+      if (p.dbg & 8) __builtin_amdgcn_s_setprio(0);
+    };
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ahead = nk - 1 - kt;
       if (NST3 >= 4 && ahead >= 2) wait_vmcnt<2 * NDMA>();
       else if (ahead >= 1) wait_vmcnt<NDMA>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
-    }
-    if (kt + NST3 - 1 < nk && !(p.dbg & 1)) issue(kt + NST3 - 1);
-    const char* sb = smem + (kt % NST3) * STAGE_BYTES;
+      if (late && kt > 0) mma();
+      if (kt + NST3 - 1 < nk) issue(kt + NST3 - 1);
+      const char* sb = smem + (kt % NST3) * STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      V8 af[MT], bf[NT];
-      if (!(p.dbg & 4) || kt == 0) {
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = *(const V8*)(sb + bro[j][ks]);
+        for (int j = 0; j < NT; ++j) bf[ks][j] = *(const V8*)(sb + bro[j][ks]);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + aro[i][ks]);
+        for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)(sb + aro[i][ks]);
       }
+      if (!late) mma();
+    }
+    if (late) mma();
+  } else {
+  // Main loop: counted wait for stage kt, ONE barrier, DMA three stages ahead, then 2 k-steps of MFMAs.
+    // (A variant with the barrier between the two k-steps and fragment reads issued one k-step ahead measured
+    //  2-5 % slower on MI355X: the compiler already overlaps the second k-step's ds_reads with the first's MFMAs.)
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ahead = nk - 1 - kt;         // later stages whose DMA may stay in flight: min(ahead, NST3 - 2)
+      if (!(p.dbg & 2)) {
+        if (NST3 >= 4 && ahead >= 2) wait_vmcnt<2 * NDMA>();
+        else if (ahead >= 1) wait_vmcnt<NDMA>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+      if (kt + NST3 - 1 < nk && !(p.dbg & 1)) issue(kt + NST3 - 1);
+      const char* sb = smem + (kt % NST3) * STAGE_BYTES;
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int ks = 0; ks < 2; ++ks) {
+        V8 af[MT], bf[NT];
+        if (!(p.dbg & 4) || kt == 0) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < NT; ++j) bf[j] = *(const V8*)(sb + bro[j][ks]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + aro[i][ks]);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[i], bf[j], acc[i][j]);
+      }
     }
   }
   __syncthreads();
@@ -628,36 +690,32 @@ bool g_use_glds = true;
 int g_dbg = 0;
 int g_variant = 0;   // 0 = heuristic, 1 = 128x128 v1, 3 = 256x256, 4 = 256x128
 
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST_>
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST_, bool STAG_ = false>
 int launch_v3(GemmP p, hipStream_t s, int mrows) {
   constexpr int lds = lds_bytes_v3(BM_, BN_, WM_ * WN_, NST_);
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_, STAG_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + BM_ - 1) / BM_;
   p.tiles_n = (p.N + BN_ - 1) / BN_;
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_, STAG_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
   return omg_check_launch("gemm_v3");
 }
 
-// tile choice: estimated time = rounds x per-tile time, where the per-tile time is (tile FLOPs) / (relative
-// MFMA rate of the configuration); 256x256 runs ~1.5x the rate of 128x128 once the grid fills the chip.
+// Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered 256x256 kernel wins whenever it can put
+// >= ~120 tiles on the 256 CUs; below that the staggered 256x128 kernel if IT reaches ~120 tiles, else the 128x128
+// kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
 int choose_variant(int mrows, int groups, int N) {
   if (g_variant != 0) return g_variant;
-  const long t128 = (long)groups * ((mrows + 127) / 128) * ((N + 127) / 128);
   const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
   const long t256x128 = (long)groups * ((mrows + 255) / 256) * ((N + 127) / 128);
-  const double r128 = (double)((t128 + 511) / 512) * 2.0 * 1.0 / 1.0;         // 2 blocks/CU resident -> rounds of 512
-  const double e128 = r128 * 1.0;
-  const double e256 = (double)((t256 + 255) / 256) * 4.0 / 1.5;
-  const double e256x128 = (double)((t256x128 + 255) / 256) * 2.0 / 1.25;
-  if (e256 <= e128 && e256 <= e256x128) return 3;
-  if (e256x128 <= e128) return 4;
+  if (N > 128 && t256 >= 120) return 9;
+  if (t256x128 >= 120) return 10;
   return 1;
 }
 
@@ -668,6 +726,8 @@ int launch(const GemmP& p, hipStream_t s) {
     int v = choose_variant(mrows, p.tile_groups, p.N);
     if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4, 4>(p, s, mrows);
     if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2, 4>(p, s, mrows);
+    if (v == 9) return launch_v3<T, CONV, 256, 256, 2, 4, 4, true>(p, s, mrows);
+    if (v == 10) return launch_v3<T, CONV, 256, 128, 4, 2, 4, true>(p, s, mrows);
     if (v == 5) return launch_v3<T, CONV, 256, 128, 2, 2, 3>(p, s, mrows);   // 4 waves x (128x64), 72 KiB: 2 blocks/CU
     if (v == 6) return launch_v3<T, CONV, 128, 256, 1, 4, 3>(p, s, mrows);
   }
