@@ -19,6 +19,7 @@
 #include "common.h"
 
 __device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
+__device__ long long omg_dbg_cycles[8][8];   // tools only: per-wave phase cycle totals of block 0 (dbg bit 16)
 
 namespace {
 
@@ -625,14 +626,21 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
           for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
       if (p.dbg & 8) __builtin_amdgcn_s_setprio(0);
     };
+    const bool prof = (p.dbg & 16) && blockIdx.x == 0;
+    long long c_wait = 0, c_bar = 0, c_mma = 0, c_dma = 0, c_rd = 0, t0 = 0, t1;
     for (int kt = 0; kt < nk; ++kt) {
       const int ahead = nk - 1 - kt;
+      if (prof) t0 = __builtin_readcyclecounter();
       if (NST3 >= 4 && ahead >= 2) wait_vmcnt<2 * NDMA>();
       else if (ahead >= 1) wait_vmcnt<NDMA>();
       else wait_vmcnt<0>();
+      if (prof) { t1 = __builtin_readcyclecounter(); c_wait += t1 - t0; t0 = t1; }
       __builtin_amdgcn_s_barrier();
+      if (prof) { t1 = __builtin_readcyclecounter(); c_bar += t1 - t0; t0 = t1; }
       if (late && kt > 0) mma();
+      if (prof) { asm volatile("s_nop 0" ::: "memory"); t1 = __builtin_readcyclecounter(); if (late) c_mma += t1 - t0; t0 = t1; }
       if (kt + NST3 - 1 < nk) issue(kt + NST3 - 1);
+      if (prof) { t1 = __builtin_readcyclecounter(); c_dma += t1 - t0; t0 = t1; }
       const char* sb = smem + (kt % NST3) * STAGE_BYTES;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -641,9 +649,15 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)(sb + aro[i][ks]);
       }
+      if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = __builtin_readcyclecounter(); c_rd += t1 - t0; t0 = t1; }
       if (!late) mma();
+      if (prof) { asm volatile("s_nop 0" ::: "memory"); t1 = __builtin_readcyclecounter(); if (!late) c_mma += t1 - t0; }
     }
     if (late) mma();
+    if (prof && lane == 0) {
+      omg_dbg_cycles[w][0] = c_wait; omg_dbg_cycles[w][1] = c_bar; omg_dbg_cycles[w][2] = c_mma; omg_dbg_cycles[w][3] = c_dma;
+      omg_dbg_cycles[w][4] = c_rd; omg_dbg_cycles[w][5] = nk;
+    }
   } else {
   // Main loop: counted wait for stage kt, ONE barrier, DMA three stages ahead, then 2 k-steps of MFMAs.
     // (A variant with the barrier between the two k-steps and fragment reads issued one k-step ahead measured
@@ -678,6 +692,223 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
 
+// ------------------------------------------------------------------------------------------------
+// v5: BK = 64 double-buffered large-tile kernel.  Phase timing of v3 (tools/gemm_phases.py) shows the 4 LDS-DMA
+// instructions of a BK=32 stage cost ~650 cycles per wave against 512 cycles of MFMA: a 64-byte row is half a cache
+// line, so every DMA instruction touches 16 lines for 1 KiB.  With 128-byte rows each instruction moves 8 WHOLE lines.
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
+__global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
+  constexpr int NST3 = 2;
+  constexpr int BK3 = 64;          // shadows the 32-wide constant: 128-byte rows = whole cache lines per DMA row
+  constexpr int NW = WM_ * WN_;
+  constexpr int MT = BM_ / WM_ / 32;             // 32-row MFMA tiles per wave (2 or 4)
+  constexpr int NT = BN_ / WN_ / 32;             // must be 2
+  static_assert(NT == 2, "wave tile N must be 64");
+  constexpr int A_BYTES = BM_ * BK3 * 2;
+  constexpr int STAGE_BYTES = (BM_ + BN_) * BK3 * 2;
+  constexpr int A_INSTR = BM_ / 8 / NW;          // one DMA instruction = 8 rows x 128 B
+  constexpr int B_INSTR = BN_ / 8 / NW;
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
+  constexpr int NDMA = A_INSTR + B_INSTR;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_per_group = p.tiles_m * p.tiles_n;
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  // grouped ordering: 8 M-tiles x all N-tiles per group, M fastest inside the group, so that the ~32 consecutive
+  // tiles an XCD receives touch ~8 A panels + <= 4..5 W panels instead of 32 + 1 (tall-skinny GEMMs re-read A per N tile)
+  int tm, tn;
+  {
+    const int per_group = 8 * p.tiles_n;
+    const int gid = t_in / per_group;
+    const int first_m = gid * 8;
+    const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int r = t_in - gid * per_group;
+    tm = first_m + (r % gsz);
+    tn = r / gsz;
+  }
+  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
+  const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
+  const int m0 = m_base + tm * BM_;
+  const int n0 = tn * BN_;
+
+  int adapter = 0;
+  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
+  const bool seg2 = (p.K2 > 0) && (adapter >= 0);
+  if (p.w_adapter_stride != 0 && adapter < 0) return;
+  const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
+  const char* W2p = p.W2 + (seg2 ? (long)adapter * p.w2_adapter_stride * 2 : 0);
+  const int a2off = (p.a2_col_block > 0) ? (n0 / p.a2_col_block) * p.K2 : 0;
+
+  const int nk1 = (p.K + BK3 - 1) / BK3;
+  const int nk2 = seg2 ? (p.K2 + BK3 - 1) / BK3 : 0;
+  const int nk = nk1 + nk2;
+
+  // ---- staging coordinates.  DMA instruction j of an operand covers rows [j*16, j*16+16); wave w issues
+  // instructions j = w + i*NW.  lane -> (row = lane>>2, 16-B position = lane&3).
+  const int prow = lane >> 3;
+  const int ppos = lane & 7;
+  const char* zero = (const char*)omg_zero_page;
+  const char* a_ptr[A_INSTR];      // plain GEMM: row base of A (segment 1) incl. source chunk
+  const char* a2_ptr[A_INSTR];
+  const char* w_ptr[B_INSTR];
+  const char* w2_ptr[B_INSTR];
+  int a_chunk[A_INSTR], w_chunk[B_INSTR];
+  int cb[A_INSTR], cy[A_INSTR], cx[A_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int r = (w + i * NW) * 8 + prow;
+    int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
+    const int c = ppos ^ ((r >> 1) & 7);
+    a_chunk[i] = c;
+    if constexpr (CONV) {
+      const int hw = p.Hout * p.Wout;
+      const int b = gm / hw; const int rem = gm - b * hw;
+      cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;
+      a_ptr[i] = nullptr; a2_ptr[i] = nullptr;
+    } else {
+      a_ptr[i] = p.A + ((long)gm * p.lda + c * 8) * 2;
+      a2_ptr[i] = p.A2 ? p.A2 + ((long)gm * p.lda2 + a2off + c * 8) * 2 : nullptr;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int r = (w + i * NW) * 8 + prow;
+    int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
+    const int c = ppos ^ ((r >> 1) & 7);
+    w_chunk[i] = c;
+    w_ptr[i] = Wp + ((long)gn * p.ldw + c * 8) * 2;
+    w2_ptr[i] = p.W2 ? W2p + ((long)gn * p.ldw2 + c * 8) * 2 : nullptr;
+  }
+  const int Ctot = p.C1 + p.C2;
+  const int cpt = CONV ? Ctot / BK3 : 1;
+  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
+
+  auto issue = [&](int kt) {
+    char* sbase = smem + (kt & 1) * STAGE_BYTES;
+    const bool s2 = kt >= nk1;
+    const int k0 = (s2 ? kt - nk1 : kt) * BK3;
+    const int Kseg = s2 ? p.K2 : p.K;
+    const bool full = (k0 + BK3) <= Kseg;              // wave-uniform: no per-lane K-tail test needed
+    if constexpr (CONV) {
+      const int tap = kt / cpt; const int cc = kt - tap * cpt;
+      const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
+      int c0 = cc * BK3;
+      const char* xsrc = p.A; int xC = p.C1;
+      if (c0 >= p.C1) { xsrc = p.X2; xC = p.C2; c0 -= p.C1; }
+      const int Hl = p.upsample ? p.Hin * 2 : p.Hin;
+      const int Wl = p.upsample ? p.Win * 2 : p.Win;
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        int iy = cy[i] * p.stride + dy - pad;
+        int ix = cx[i] * p.stride + dx - pad;
+        const bool ok = (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
+        if (p.upsample) { iy >>= 1; ix >>= 1; }
+        const long pix = ((long)cb[i] * p.Hin + iy) * p.Win + ix;
+        const char* asrc = ok ? xsrc + (pix * xC + c0 + a_chunk[i] * 8) * 2 : zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_INSTR; ++i) {
+        const char* wsrc = w_ptr[i] + (long)kt * (BK3 * 2);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const char* asrc = (s2 ? a2_ptr[i] : a_ptr[i]) + k0 * 2;
+        if (!full && (k0 + a_chunk[i] * 8) >= Kseg) asrc = zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_INSTR; ++i) {
+        const char* wsrc = (s2 ? w2_ptr[i] : w_ptr[i]) + k0 * 2;
+        if (!full && (k0 + w_chunk[i] * 8) >= Kseg) wsrc = zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  const int wm = w / WN_, wn = w % WN_;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  using V8 = typename Vec<T>::v8;
+
+  // stage-relative fragment offsets (ks = 0/1 differ by chunk ^ 2 -> precompute both)
+  int aro[MT][4], bro[NT][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int kc = ks * 2 + hi;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ra = wm * (MT * 32) + i * 32 + l31;
+      aro[i][ks] = ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int rb = wn * 64 + j * 32 + l31;
+      bro[j][ks] = A_BYTES + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4);
+    }
+  }
+
+  issue(0);
+
+  // Double-buffered BK=64 stages (2 x 64 KiB for the 256x256 tile) + two-group stagger at half-stage granularity:
+  //   early waves: DMA(kt+1), read half 0, MFMA half 0, read half 1, MFMA half 1
+  //   late  waves: MFMA half 1 of stage kt-1, DMA(kt+1), read half 0, MFMA half 0, read half 1
+  // so on every SIMD one wave is in an 8-MFMA x2 section while its partner issues DMA / fragment reads.
+  const bool late = w >= NW / 2;
+  V8 af[2][MT], bf[2][NT];
+  auto mma = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
+  };
+  auto rd = [&](const char* sb, int half) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[ks][j] = *(const V8*)(sb + bro[j][half * 2 + ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)(sb + aro[i][half * 2 + ks]);
+    }
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();                       // DMA(kt) was issued one stage ago; nothing newer is in flight
+    __builtin_amdgcn_s_barrier();
+    if (late && kt > 0) mma();
+    if (kt + 1 < nk) issue(kt + 1);
+    const char* sb = smem + (kt & 1) * STAGE_BYTES;
+    rd(sb, 0);
+    mma();
+    rd(sb, 1);
+    if (!late) mma();
+  }
+  if (late) mma();
+  __syncthreads();
+  epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
+}
+
 constexpr int lds_bytes_v3(int bm, int bn, int nw, int nst) {
   const int ring = nst * (bm + bn) * BK3 * 2;
   const int epi = nw * 32 * STAGE_LD * 4;
@@ -707,15 +938,34 @@ int launch_v3(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v3");
 }
 
-// Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered 256x256 kernel wins whenever it can put
+template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
+int launch_v5(GemmP p, hipStream_t s, int mrows) {
+  constexpr int ring = 2 * (BM_ + BN_) * 64 * 2;
+  constexpr int epi = WM_ * WN_ * 32 * STAGE_LD * 4;
+  constexpr int lds = ring > epi ? ring : epi;
+  static bool attr = false;
+  if (!attr) {
+    attr = true;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<T, CONV, BM_, BN_, WM_, WN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  p.tiles_m = (mrows + BM_ - 1) / BM_;
+  p.tiles_n = (p.N + BN_ - 1) / BN_;
+  p.dbg = g_dbg;
+  const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
+  if (grid <= 0) return OMG_OK;
+  OMG_LAUNCH((gemm_kernel_v5<T, CONV, BM_, BN_, WM_, WN_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
+  return omg_check_launch("gemm_v5");
+}
+
+// Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered BK=64 256x256 kernel (v5) wins whenever it can put
 // >= ~120 tiles on the 256 CUs; below that the staggered 256x128 kernel if IT reaches ~120 tiles, else the 128x128
 // kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
 int choose_variant(int mrows, int groups, int N) {
   if (g_variant != 0) return g_variant;
   const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
   const long t256x128 = (long)groups * ((mrows + 255) / 256) * ((N + 127) / 128);
-  if (N > 128 && t256 >= 120) return 9;
-  if (t256x128 >= 120) return 10;
+  if (N > 128 && t256 >= 120) return 11;     // 256x256, BK=64 double buffer, staggered
+  if (t256x128 >= 120) return 12;            // 256x128, same structure
   return 1;
 }
 
@@ -726,6 +976,8 @@ int launch(const GemmP& p, hipStream_t s) {
     int v = choose_variant(mrows, p.tile_groups, p.N);
     if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4, 4>(p, s, mrows);
     if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2, 4>(p, s, mrows);
+    if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
+    if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);
     if (v == 9) return launch_v3<T, CONV, 256, 256, 2, 4, 4, true>(p, s, mrows);
     if (v == 10) return launch_v3<T, CONV, 256, 128, 4, 2, 4, true>(p, s, mrows);
     if (v == 5) return launch_v3<T, CONV, 256, 128, 2, 2, 3>(p, s, mrows);   // 4 waves x (128x64), 72 KiB: 2 blocks/CU
@@ -758,6 +1010,9 @@ void ensure_attrs() {
 
 }  // namespace
 
+extern "C" int omg_debug_read_cycles(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(omg_dbg_cycles), sizeof(long long) * 64);
+}
 extern "C" void omg_debug_set_glds(int on) { g_use_glds = on != 0; }
 extern "C" void omg_debug_set_gemm_variant(int v) { g_variant = v & 0xff; g_dbg = v >> 8; }
 
