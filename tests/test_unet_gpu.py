@@ -104,3 +104,32 @@ def test_unet_protocol_mode_general_mapper(dev, dtype):
         err = (y - ref).abs().max().item()
         print(f"protocol step {step}: max|d|={err:.3e}")
         assert err < TOL[dtype]
+
+
+def test_ip_adapter_processor_matches_reference_golden(dev):
+    """omg_amd.attention.IPAttnProcessor2_0 / FusedAttnProcessor on an omg_amd Attention module vs outputs produced by
+    the REFERENCE's own IPAttnProcessor2_0 / AttnProcessor2_0 classes (tests/golden/ip_adapter_golden.npz)."""
+    import os
+    import numpy as np
+    from omg_amd.attention import Attention, FusedAttnProcessor, IPAttnProcessor2_0
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ip_adapter_golden.npz"))
+    C, ctx, heads, ntok = (int(v) for v in g["meta"])
+    for dtype, tol in ((torch.float16, 4e-3), (torch.bfloat16, 3e-2)):
+        T = lambda k: torch.from_numpy(g[k]).to(dev).to(dtype)
+        attn = Attention(C, ctx, heads, dtype=dtype, device=dev)
+        attn.load_state_dict({"to_q.weight": T("attn.to_q.weight"), "to_k.weight": T("attn.to_k.weight"), "to_v.weight": T("attn.to_v.weight"),
+                              "to_out.0.weight": T("attn.to_out.0.weight"), "to_out.0.bias": T("attn.to_out.0.bias")})
+        proc = IPAttnProcessor2_0(C, ctx, scale=0.8, num_tokens=ntok, dtype=dtype, device=dev)
+        proc.load_state_dict({"to_k_ip.weight": T("to_k_ip"), "to_v_ip.weight": T("to_v_ip")})
+        attn.set_processor(proc)
+        y = attn(T("hidden_states"), encoder_hidden_states=T("encoder_hidden_states"))
+        err = (y.float().cpu() - torch.from_numpy(g["out_cross"])).abs().max().item()
+        assert err < tol, (dtype, err)
+        sattn = Attention(C, None, heads, dtype=dtype, device=dev)
+        sattn.load_state_dict({"to_q.weight": T("self_attn.to_q.weight"), "to_k.weight": T("self_attn.to_k.weight"),
+                               "to_v.weight": T("self_attn.to_v.weight"), "to_out.0.weight": T("self_attn.to_out.0.weight"),
+                               "to_out.0.bias": T("self_attn.to_out.0.bias")})
+        sattn.set_processor(FusedAttnProcessor())
+        ys = sattn(T("hidden_states"))
+        errs = (ys.float().cpu() - torch.from_numpy(g["out_self"])).abs().max().item()
+        assert errs < tol, (dtype, errs)
