@@ -909,6 +909,163 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
 
+// ------------------------------------------------------------------------------------------------
+// v6: v5's structure (256x256x64 tile, double buffer, two-group stagger) with the stage's 8 LDS-DMA instructions spread
+// one by one between groups of 4 MFMAs instead of issued as a burst.  Phase timing of v5 (tools/gemm_phases.py): a wave
+// spends ~100-170 cycles BLOCKED on each global_load_lds when all waves of a group issue their 8 together (the texture
+// addresser queues), ~1100 cycles per stage against 1024 cycles of MFMA.  Plain GEMM only (K % 64 == 0, no LoRA segment).
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
+  constexpr int BM_ = 256, BN_ = 256, BKc = 64, NW = 8, MT = 4, NT = 2;
+  constexpr int A_BYTES = BM_ * BKc * 2;
+  constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_per_group = p.tiles_m * p.tiles_n;
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  int tm, tn;
+  {
+    const int per_group = 8 * p.tiles_n;
+    const int gid = t_in / per_group;
+    const int first_m = gid * 8;
+    const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int r = t_in - gid * per_group;
+    tm = first_m + (r % gsz);
+    tn = r / gsz;
+  }
+  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
+  const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
+  const int m0 = m_base + tm * BM_;
+  const int n0 = tn * BN_;
+  int adapter = 0;
+  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
+  if (p.w_adapter_stride != 0 && adapter < 0) return;
+  const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
+  const int nk = p.K / BKc;
+
+  // 8 DMA streams per wave: A rows (w + 8i)*8 + lane/8, i = 0..3, then W rows likewise; 128 bytes further per stage
+  const int prow = lane >> 3, ppos = lane & 7;
+  // buffer addressing: SGPR descriptor + 32-bit per-lane offset + SGPR stage offset -> no per-stage address VALU at all
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, 0x7fffffff, 0x00020000);
+  int voff[8];
+  int ldo[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (w + i * NW) * 8 + prow;
+    const int c = ppos ^ ((r >> 1) & 7);
+    int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
+    int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
+    voff[i] = (int)(((long)gm * p.lda + c * 8) * 2);
+    voff[4 + i] = (int)(((long)gn * p.ldw + c * 8) * 2);
+    ldo[i] = (w + i * NW) * 1024;
+    ldo[4 + i] = A_BYTES + (w + i * NW) * 1024;
+  }
+
+  const int wm = w >> 2, wn = w & 3;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  using V8 = typename Vec<T>::v8;
+  int aro[MT][4], bro[NT][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int kc = ks * 2 + hi;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ra = wm * 128 + i * 32 + l31;
+      aro[i][ks] = ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int rb = wn * 64 + j * 32 + l31;
+      bro[j][ks] = A_BYTES + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4);
+    }
+  }
+
+  const bool late = w >= 4;
+  V8 af[2][MT], bf[2][NT];
+#define OMG_DMA(i_, nb_)                                                                                     \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((i_) < 4 ? rsA : rsW, (lds_ptr_t)((nb_) + ldo[i_]), 16, voff[i_], koff, 0, 0)
+#define OMG_DMA2(q_, nb_)                                                                                    \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(late ? rsW : rsA, (lds_ptr_t)((nb_) + (late ? ldo[4 + (q_)] : ldo[q_])), 16,                \
+                                           late ? voff[4 + (q_)] : voff[q_], koff, 0, 0)
+#define OMG_Q(q_)                                                                                            \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int i = ((q_) & 1) * 2; i < ((q_) & 1) * 2 + 2; ++i)                              \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
+        acc[i][j] = Vec<T>::mfma32(af[(q_) >> 1][i], bf[(q_) >> 1][j], acc[i][j]);                           \
+  } while (0)
+#define OMG_RD(sb_, half_)                                                                                   \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j) bf[ks][j] = *(const V8*)((sb_) + bro[j][(half_) * 2 + ks]); \
+      _Pragma("unroll") for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)((sb_) + aro[i][(half_) * 2 + ks]); \
+    }                                                                                                        \
+  } while (0)
+  // prologue: stage 0 as a burst
+  int koff = 0;
+  OMG_DMA(0, smem); OMG_DMA(1, smem); OMG_DMA(2, smem); OMG_DMA(3, smem);
+  OMG_DMA(4, smem); OMG_DMA(5, smem); OMG_DMA(6, smem); OMG_DMA(7, smem);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const char* sb = smem + (kt & 1) * STAGE_BYTES;
+    char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
+    const bool nxt = kt + 1 < nk;
+    koff = (kt + 1) * (BKc * 2);
+    // block A of the late group: previous stage's second half + DMA 0..3
+    if (late) {
+      if (kt > 0) {
+        OMG_Q(0); if (nxt) OMG_DMA(0, nb);
+        OMG_Q(1); if (nxt) OMG_DMA(1, nb);
+        OMG_Q(2); if (nxt) OMG_DMA(2, nb);
+        OMG_Q(3); if (nxt) OMG_DMA(3, nb);
+      } else if (nxt) {
+        OMG_DMA(0, nb); OMG_DMA(1, nb); OMG_DMA(2, nb); OMG_DMA(3, nb);
+      }
+    }
+    OMG_RD(sb, 0);
+    // first half: block A of the early group (DMA 0..3) = block B of the late group (DMA 4..7)
+    OMG_Q(0); if (nxt) OMG_DMA2(0, nb);
+    OMG_Q(1); if (nxt) OMG_DMA2(1, nb);
+    OMG_Q(2); if (nxt) OMG_DMA2(2, nb);
+    OMG_Q(3); if (nxt) OMG_DMA2(3, nb);
+    OMG_RD(sb, 1);
+    if (!late) {
+      OMG_Q(0); if (nxt) OMG_DMA(4, nb);
+      OMG_Q(1); if (nxt) OMG_DMA(5, nb);
+      OMG_Q(2); if (nxt) OMG_DMA(6, nb);
+      OMG_Q(3); if (nxt) OMG_DMA(7, nb);
+    }
+  }
+  if (late) { OMG_Q(0); OMG_Q(1); OMG_Q(2); OMG_Q(3); }
+#undef OMG_DMA
+#undef OMG_DMA2
+#undef OMG_Q
+#undef OMG_RD
+  __syncthreads();
+  epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
+}
+
 constexpr int lds_bytes_v3(int bm, int bn, int nw, int nst) {
   const int ring = nst * (bm + bn) * BK3 * 2;
   const int epi = nw * 32 * STAGE_LD * 4;
@@ -957,6 +1114,23 @@ int launch_v5(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v5");
 }
 
+template <typename T>
+int launch_v6(GemmP p, hipStream_t s, int mrows) {
+  constexpr int lds = 2 * (256 + 256) * 64 * 2;
+  static bool attr = false;
+  if (!attr) {
+    attr = true;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v6<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  p.tiles_m = (mrows + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  p.dbg = g_dbg;
+  const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
+  if (grid <= 0) return OMG_OK;
+  OMG_LAUNCH((gemm_kernel_v6<T>), dim3(grid), dim3(512), lds, s, p);
+  return omg_check_launch("gemm_v6");
+}
+
 // Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered BK=64 256x256 kernel (v5) wins whenever it can put
 // >= ~120 tiles on the 256 CUs; below that the staggered 256x128 kernel if IT reaches ~120 tiles, else the 128x128
 // kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
@@ -976,6 +1150,8 @@ int launch(const GemmP& p, hipStream_t s) {
     int v = choose_variant(mrows, p.tile_groups, p.N);
     if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4, 4>(p, s, mrows);
     if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2, 4>(p, s, mrows);
+    if constexpr (!CONV) { if (v == 13 && p.K % 64 == 0 && p.K2 == 0) return launch_v6<T>(p, s, mrows); }
+    if (v == 13) v = 11;
     if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
     if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);
     if (v == 9) return launch_v3<T, CONV, 256, 256, 2, 4, 4, true>(p, s, mrows);
