@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--cpu-latent", type=int, default=64, choices=[64, 128])
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (NOT a valid benchmark)")
     ap.add_argument("--images-per-step", type=int, default=4, help="independent requests run in lock-step per step (one batched UNet forward)")
+    ap.add_argument("--by-shape", default="", help="also write the roofline leg's per-shape table (ms per bench step, TF/s) to this file")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
 
@@ -162,8 +163,8 @@ def main():
                                lora_list=["concept0", "concept1"], styleL=False, fusion_start=fusion_start)
             ops.set_profiler(None)
             torch.cuda.synchronize()
-            return prof.summary()
-        sp, sf = instrumented(99), instrumented(-1)
+            return prof.summary(), dict(prof.by_tag())
+        (sp, tp), (sf, tf) = instrumented(99), instrumented(-1)
         n_f = max(0, args.denoise_steps - 16)
         n_p = args.denoise_steps - n_f
         def comb(kind, key):
@@ -171,12 +172,24 @@ def main():
         g_ms, g_fl, g_n = comb("gemm", "ms"), comb("gemm", "flops"), comb("gemm", "launches")
         a_ms, a_fl = comb("attn", "ms"), comb("attn", "flops")
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_v5 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)",
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)",
                            "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": None,
                            "launches_per_step": g_n, "avg_launch_us": 1e3 * g_ms / g_n, "avg_launch_gflop": g_fl / g_n / 1e9,
                            "gemm_ms_per_step": g_ms,
                            "sample": f"HIP events around each launch (eager), 2 plain + 2 fused denoising steps weighted {n_p}:{n_f} as in the timed workload",
                            "attn_kernel": {"achieved": a_fl / (a_ms * 1e-3) / 1e12, "ms_per_step": a_ms}}
+        if args.by_shape:
+            rows = []
+            for key in set(tp) | set(tf):
+                z = dict(launches=0, ms=0.0, flops=0.0)
+                a, b = tp.get(key, z), tf.get(key, z)
+                rows.append((key, *[(n_p * a[k] + n_f * b[k]) / 2.0 for k in ("ms", "flops", "launches")]))
+            rows.sort(key=lambda r: -r[1])
+            tot = sum(r[1] for r in rows)
+            with open(args.by_shape, "w") as f:
+                f.write(f"# per bench step ({ips} images): kind, shape tag, launches, ms, share, TF/s; total {tot:.1f} ms\n")
+                for key, ms, fl, n in rows:
+                    f.write(f"{key[0]:5s} {str(key[1]):56s} n={n:7.0f} ms={ms:9.2f} ({100 * ms / tot:4.1f}%) {fl / ms / 1e9 if ms else 0:7.1f} TF/s\n")
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -360,8 +360,12 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, in
   const bool geglu = p.act == OMG_ACT_GEGLU;
   if (!geglu && p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
 #pragma unroll
+  // The staging area is private to the wave: LDS executes one wave's instructions in order, so a compiler-level fence
+  // between the slab's writes and its reads is all the synchronisation needed (the caller has already joined the block
+  // after the K loop).  Block barriers here would re-serialise the two staggered wave groups eight times per tile.
   for (int i = 0; i < MT; ++i) {
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -369,7 +373,8 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, in
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
       }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (geglu) {
       const int s4 = lane & 3, r4 = lane >> 2;
 #pragma unroll
@@ -909,14 +914,40 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
 
+// 16 bytes per lane, global -> LDS, through a buffer descriptor.  A non-template wrapper on purpose: with value-dependent
+// arguments the builtin's checks are deferred to instantiation time, where the host pass of hipcc silently drops the kernel.
+OMG_DEV void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, voff, soff, 0, 0);
+}
+
+// conv A-operand byte offset of one output pixel's tap inside the (logical, possibly 2x-upsampled) input image;
+// out-of-image taps get an offset beyond the buffer's num_records, which the buffer load turns into zeros
+OMG_DEV int conv_voff(int b, int oy, int ox, int ch_bytes, int stride, int dy, int dx, int Hl, int Wl, int ups, int Hin, int Win,
+                      int pix_bytes, int c0_bytes) {
+  int iy = oy * stride + dy, ix = ox * stride + dx;
+  const bool ok = (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
+  if (ups) { iy >>= 1; ix >>= 1; }
+  const int pix = (b * Hin + iy) * Win + ix;
+  return ok ? pix * pix_bytes + c0_bytes + ch_bytes : 0x7ffffff0;
+}
+
 // ------------------------------------------------------------------------------------------------
-// v6: v5's structure (256x256x64 tile, double buffer, two-group stagger) with the stage's 8 LDS-DMA instructions spread
-// one by one between groups of 4 MFMAs instead of issued as a burst.  Phase timing of v5 (tools/gemm_phases.py): a wave
-// spends ~100-170 cycles BLOCKED on each global_load_lds when all waves of a group issue their 8 together (the texture
-// addresser queues), ~1100 cycles per stage against 1024 cycles of MFMA.  Plain GEMM only (K % 64 == 0, no LoRA segment).
-template <typename T>
+// v6: v5's structure (256 x {256,128} x 64 tile, double buffer, two-group stagger) with the stage's LDS-DMA instructions
+// spread one by one between pairs/quartets of MFMAs instead of issued as a burst, and buffer-descriptor addressing
+// (SGPR descriptor + 32-bit per-lane offset + SGPR stage offset: no per-stage 64-bit address VALU; out-of-image conv taps
+// and the K tail are simply out-of-range offsets, which the buffer unit returns as zeros).  Phase timing of v5
+// (tools/gemm_phases.py): a wave spent ~100-170 cycles BLOCKED on each global_load_lds when the waves of a group issued
+// their 8 together (the texture addresser queues), ~1100 cycles per stage against 1024 cycles of MFMA.
+//   MT = 4: 256x256, waves 2(M) x 4(N), wave tile 128x64, 4+4 DMA / wave / stage, one DMA per 4 MFMAs
+//   MT = 2: 256x128, waves 4(M) x 2(N), wave tile  64x64, 4+2 DMA / wave / stage, one DMA per 2 MFMAs (3 of 4 slots)
+// LoRA second K-segment is not handled here (v5/v1 do that).
+template <typename T, bool CONV, int MT>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
-  constexpr int BM_ = 256, BN_ = 256, BKc = 64, NW = 8, MT = 4, NT = 2;
+  constexpr int BM_ = 256, BN_ = MT == 4 ? 256 : 128, BKc = 64, NW = 8, NT = 2;
+  constexpr int WN_ = MT == 4 ? 4 : 2;
+  constexpr int BI = BN_ / 8 / NW;                 // W DMA instructions per wave per stage (4 or 2)
+  constexpr int ND = 4 + BI;                       // all DMA instructions per wave per stage (8 or 6)
+  constexpr int HB = ND / 2;                       // per MFMA block (4 or 3)
   constexpr int A_BYTES = BM_ * BKc * 2;
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
 
@@ -954,28 +985,45 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
   if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
   if (p.w_adapter_stride != 0 && adapter < 0) return;
   const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
-  const int nk = p.K / BKc;
+  const int nk = (p.K + BKc - 1) / BKc;
 
-  // 8 DMA streams per wave: A rows (w + 8i)*8 + lane/8, i = 0..3, then W rows likewise; 128 bytes further per stage
+  const int Ctot = p.C1 + p.C2;
+  // num_records: exact byte sizes, so that any offset at or beyond them reads as zero
+  const long a_bytes = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C1 * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(a_bytes < 0x7fffff00 ? a_bytes : 0x7fffff00), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(CONV && p.X2 ? p.X2 : p.A), 0,
+      CONV ? (int)((long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C2 * 2) : 0, 0x00020000);
+  const long w_bytes = ((long)(p.N - 1) * p.ldw + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)w_bytes, 0x00020000);
+
   const int prow = lane >> 3, ppos = lane & 7;
-  // buffer addressing: SGPR descriptor + 32-bit per-lane offset + SGPR stage offset -> no per-stage address VALU at all
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, 0x7fffffff, 0x00020000);
-  int voff[8];
-  int ldo[8];
+  int voffA[4], voffW[BI], ldoA[4], ldoW[BI];
+  int cb[4], cy[4], cx[4], cch[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (w + i * NW) * 8 + prow;
     const int c = ppos ^ ((r >> 1) & 7);
     int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
+    ldoA[i] = (w + i * NW) * 1024;
+    if constexpr (CONV) {
+      const int hw = p.Hout * p.Wout;
+      const int b = gm / hw; const int rem = gm - b * hw;
+      cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout; cch[i] = c * 16;
+      voffA[i] = 0;
+    } else {
+      voffA[i] = (int)(((long)gm * p.lda + c * 8) * 2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int r = (w + i * NW) * 8 + prow;
+    const int c = ppos ^ ((r >> 1) & 7);
     int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
-    voff[i] = (int)(((long)gm * p.lda + c * 8) * 2);
-    voff[4 + i] = (int)(((long)gn * p.ldw + c * 8) * 2);
-    ldo[i] = (w + i * NW) * 1024;
-    ldo[4 + i] = A_BYTES + (w + i * NW) * 1024;
+    voffW[i] = (int)(((long)gn * p.ldw + c * 8) * 2);
+    ldoW[i] = A_BYTES + (w + i * NW) * 1024;
   }
 
-  const int wm = w >> 2, wn = w & 3;
+  const int wm = w / WN_, wn = w % WN_;
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -990,7 +1038,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
     const int kc = ks * 2 + hi;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int ra = wm * 128 + i * 32 + l31;
+      const int ra = wm * (MT * 32) + i * 32 + l31;
       aro[i][ks] = ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4);
     }
 #pragma unroll
@@ -1000,18 +1048,56 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
     }
   }
 
+  // per-stage uniform state of the NEXT stage's loads (set by `prep`)
+  int koff = 0;                         // byte offset of the stage inside a W row (and an A row of the plain GEMM)
+  int tap_dy = 0, tap_dx = 0, c0b = 0, xCb = 0;   // conv: tap, byte offset of the channel slice, bytes per pixel
+  bool x2 = false;
+  const int cpt = CONV ? Ctot / BKc : 1;
+  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
+  const int Hl = CONV ? (p.upsample ? p.Hin * 2 : p.Hin) : 0;
+  const int Wl = CONV ? (p.upsample ? p.Win * 2 : p.Win) : 0;
+#define OMG_PREP(kt_)                                                                                      \
+  do {                                                                                                     \
+    koff = (kt_) * (BKc * 2);                                                                              \
+    if constexpr (CONV) {                                                                                  \
+      const int tap = (kt_) / cpt; const int cc = (kt_) - tap * cpt;                                       \
+      tap_dy = tap / p.ksize - pad; tap_dx = tap - (tap / p.ksize) * p.ksize - pad;                        \
+      int c0 = cc * BKc;                                                                                   \
+      x2 = c0 >= p.C1;                                                                                     \
+      if (x2) c0 -= p.C1;                                                                                  \
+      c0b = c0 * 2; xCb = (x2 ? p.C2 : p.C1) * 2;                                                          \
+    }                                                                                                      \
+  } while (0)
+  // byte offset of A row block i's 16 bytes for the prepared stage (i is a compile-time constant at every use)
+#define OMG_AVO(i_) (CONV ? conv_voff(cb[i_], cy[i_], cx[i_], cch[i_], p.stride, tap_dy, tap_dx, Hl, Wl, p.upsample, p.Hin, p.Win, xCb, c0b) : voffA[i_])
+
   const bool late = w >= 4;
   V8 af[2][MT], bf[2][NT];
-#define OMG_DMA(i_, nb_)                                                                                     \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds((i_) < 4 ? rsA : rsW, (lds_ptr_t)((nb_) + ldo[i_]), 16, voff[i_], koff, 0, 0)
+  // DMA instruction d of the stage: d < 4 -> A row block d, else W row block d-4
+#define OMG_ISA(d_) ((d_) < 4)
+#define OMG_AI(d_) ((d_) < 4 ? (d_) : 0)
+#define OMG_WI(d_) ((d_) >= 4 ? (d_) - 4 : 0)
+#define OMG_VO(d_) (OMG_ISA(d_) ? OMG_AVO(OMG_AI(d_)) : voffW[OMG_WI(d_)])
+#define OMG_LO(d_) (OMG_ISA(d_) ? ldoA[OMG_AI(d_)] : ldoW[OMG_WI(d_)])
+#define OMG_RS(d_) (OMG_ISA(d_) ? ((CONV && x2) ? rsA2 : rsA) : rsW)
+#define OMG_SO(d_) ((OMG_ISA(d_) && CONV) ? 0 : koff)
+#define OMG_DMA(d_, nb_)                                                                                     \
+  dma16(OMG_RS(d_), (nb_) + OMG_LO(d_), OMG_VO(d_), OMG_SO(d_))
+  // one instruction shared by both groups: the early group issues d = q, the late group d = HB + q
 #define OMG_DMA2(q_, nb_)                                                                                    \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(late ? rsW : rsA, (lds_ptr_t)((nb_) + (late ? ldo[4 + (q_)] : ldo[q_])), 16,                \
-                                           late ? voff[4 + (q_)] : voff[q_], koff, 0, 0)
+  dma16(late ? OMG_RS(HB + (q_)) : OMG_RS(q_), (nb_) + (late ? OMG_LO(HB + (q_)) : OMG_LO(q_)),              \
+        late ? OMG_VO(HB + (q_)) : OMG_VO(q_), late ? OMG_SO(HB + (q_)) : OMG_SO(q_))
+  // MFMA slot q (0..3) of a half: MT*NT*2/4 MFMAs
 #define OMG_Q(q_)                                                                                            \
   do {                                                                                                       \
-    _Pragma("unroll") for (int i = ((q_) & 1) * 2; i < ((q_) & 1) * 2 + 2; ++i)                              \
+    if constexpr (MT == 4) {                                                                                 \
+      _Pragma("unroll") for (int i = ((q_) & 1) * 2; i < ((q_) & 1) * 2 + 2; ++i)                            \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
+          acc[i][j] = Vec<T>::mfma32(af[(q_) >> 1][i], bf[(q_) >> 1][j], acc[i][j]);                         \
+    } else {                                                                                                 \
       _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
-        acc[i][j] = Vec<T>::mfma32(af[(q_) >> 1][i], bf[(q_) >> 1][j], acc[i][j]);                           \
+        acc[(q_) & 1][j] = Vec<T>::mfma32(af[(q_) >> 1][(q_) & 1], bf[(q_) >> 1][j], acc[(q_) & 1][j]);      \
+    }                                                                                                        \
   } while (0)
 #define OMG_RD(sb_, half_)                                                                                   \
   do {                                                                                                       \
@@ -1020,10 +1106,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
       _Pragma("unroll") for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)((sb_) + aro[i][(half_) * 2 + ks]); \
     }                                                                                                        \
   } while (0)
+
   // prologue: stage 0 as a burst
-  int koff = 0;
+  OMG_PREP(0);
   OMG_DMA(0, smem); OMG_DMA(1, smem); OMG_DMA(2, smem); OMG_DMA(3, smem);
-  OMG_DMA(4, smem); OMG_DMA(5, smem); OMG_DMA(6, smem); OMG_DMA(7, smem);
+  OMG_DMA(4, smem); OMG_DMA(5, smem);
+  if constexpr (ND == 8) { OMG_DMA(6, smem); OMG_DMA(7, smem); }
 
   for (int kt = 0; kt < nk; ++kt) {
     wait_vmcnt<0>();
@@ -1031,30 +1119,30 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
     const char* sb = smem + (kt & 1) * STAGE_BYTES;
     char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
     const bool nxt = kt + 1 < nk;
-    koff = (kt + 1) * (BKc * 2);
-    // block A of the late group: previous stage's second half + DMA 0..3
-    if (late) {
+    OMG_PREP(kt + 1);
+    if (late) {      // block 0 of the late group: previous stage's second half + DMA 0..HB-1
       if (kt > 0) {
         OMG_Q(0); if (nxt) OMG_DMA(0, nb);
         OMG_Q(1); if (nxt) OMG_DMA(1, nb);
         OMG_Q(2); if (nxt) OMG_DMA(2, nb);
-        OMG_Q(3); if (nxt) OMG_DMA(3, nb);
+        OMG_Q(3); if constexpr (HB == 4) { if (nxt) OMG_DMA(3, nb); }
       } else if (nxt) {
-        OMG_DMA(0, nb); OMG_DMA(1, nb); OMG_DMA(2, nb); OMG_DMA(3, nb);
+        OMG_DMA(0, nb); OMG_DMA(1, nb); OMG_DMA(2, nb);
+        if constexpr (HB == 4) OMG_DMA(3, nb);
       }
     }
     OMG_RD(sb, 0);
-    // first half: block A of the early group (DMA 0..3) = block B of the late group (DMA 4..7)
+    // first half of stage kt: block 0 of the early group (DMA q) == block 1 of the late group (DMA HB+q)
     OMG_Q(0); if (nxt) OMG_DMA2(0, nb);
     OMG_Q(1); if (nxt) OMG_DMA2(1, nb);
     OMG_Q(2); if (nxt) OMG_DMA2(2, nb);
-    OMG_Q(3); if (nxt) OMG_DMA2(3, nb);
+    OMG_Q(3); if constexpr (HB == 4) { if (nxt) OMG_DMA2(3, nb); }
     OMG_RD(sb, 1);
     if (!late) {
-      OMG_Q(0); if (nxt) OMG_DMA(4, nb);
-      OMG_Q(1); if (nxt) OMG_DMA(5, nb);
-      OMG_Q(2); if (nxt) OMG_DMA(6, nb);
-      OMG_Q(3); if (nxt) OMG_DMA(7, nb);
+      OMG_Q(0); if (nxt) OMG_DMA(HB + 0, nb);
+      OMG_Q(1); if (nxt) OMG_DMA(HB + 1, nb);
+      OMG_Q(2); if (nxt) OMG_DMA(HB + 2, nb);
+      OMG_Q(3); if constexpr (HB == 4) { if (nxt) OMG_DMA(HB + 3, nb); }
     }
   }
   if (late) { OMG_Q(0); OMG_Q(1); OMG_Q(2); OMG_Q(3); }
@@ -1062,6 +1150,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
 #undef OMG_DMA2
 #undef OMG_Q
 #undef OMG_RD
+#undef OMG_ISA
+#undef OMG_AI
+#undef OMG_WI
+#undef OMG_VO
+#undef OMG_LO
+#undef OMG_RS
+#undef OMG_SO
+#undef OMG_PREP
+#undef OMG_AVO
   __syncthreads();
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
@@ -1114,20 +1211,23 @@ int launch_v5(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v5");
 }
 
-template <typename T>
+template <typename T, bool CONV, int MT>
 int launch_v6(GemmP p, hipStream_t s, int mrows) {
-  constexpr int lds = 2 * (256 + 256) * 64 * 2;
+  constexpr int BN_ = MT == 4 ? 256 : 128;
+  constexpr int ring = 2 * (256 + BN_) * 64 * 2;
+  constexpr int epi = 8 * 32 * STAGE_LD * 4;
+  constexpr int lds = ring > epi ? ring : epi;
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v6<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v6<T, CONV, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
+  p.tiles_n = (p.N + BN_ - 1) / BN_;
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v6<T>), dim3(grid), dim3(512), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v6<T, CONV, MT>), dim3(grid), dim3(512), lds, s, p);
   return omg_check_launch("gemm_v6");
 }
 
@@ -1138,8 +1238,12 @@ int choose_variant(int mrows, int groups, int N) {
   if (g_variant != 0) return g_variant;
   const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
   const long t256x128 = (long)groups * ((mrows + 255) / 256) * ((N + 127) / 128);
-  if (N > 128 && t256 >= 120) return 11;     // 256x256, BK=64 double buffer, staggered
-  if (t256x128 >= 120) return 12;            // 256x128, same structure
+  // rounds of 256 one-block CUs x time per tile (a 256x128 tile costs ~0.58 of a 256x256 one: tools/shape_sweep.py);
+  // the narrow tile wins when N pads badly to 256 (320 -> 512) or its tile count fills the last round better
+  const double c256 = (double)((t256 + 255) / 256);
+  const double c128 = (double)((t256x128 + 255) / 256) * 0.58;
+  if (N > 128 && t256 >= 120 && c256 <= c128 * 1.06) return 13;   // 256x256, BK=64 double buffer, staggered, interleaved DMA
+  if (t256x128 >= 120) return 14;                                  // 256x128, same structure
   return 1;
 }
 
@@ -1150,8 +1254,11 @@ int launch(const GemmP& p, hipStream_t s) {
     int v = choose_variant(mrows, p.tile_groups, p.N);
     if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4, 4>(p, s, mrows);
     if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2, 4>(p, s, mrows);
-    if constexpr (!CONV) { if (v == 13 && p.K % 64 == 0 && p.K2 == 0) return launch_v6<T>(p, s, mrows); }
-    if (v == 13) v = 11;
+    // v6 (interleaved DMA) handles everything except the LoRA second K-segment and > 2 GiB operands
+    const long lim = 0x7fff0000L;
+    const long a_sz = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 : (long)p.M * p.lda * 2;
+    const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim;
+    if (v == 13 || v == 14) { if (v6ok) return v == 13 ? launch_v6<T, CONV, 4>(p, s, mrows) : launch_v6<T, CONV, 2>(p, s, mrows); v = (v == 13) ? 11 : 12; }
     if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
     if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);
     if (v == 9) return launch_v3<T, CONV, 256, 256, 2, 4, 4, true>(p, s, mrows);
