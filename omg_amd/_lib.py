@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libomg_hip.so")
+LIB_PATH = os.environ.get("OMG_HIP_LIB") or os.path.join(_HERE, "csrc", "libomg_hip.so")   # override: A/B builds in tools/
 
 OMG_F16, OMG_BF16, OMG_F32 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2

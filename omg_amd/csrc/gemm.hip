@@ -19,7 +19,8 @@
 #include "common.h"
 
 __device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
-__device__ long long omg_dbg_cycles[8][8];   // tools only: per-wave phase cycle totals of block 0 (dbg bit 16)
+__device__ long long omg_dbg_cycles[8][8];
+__device__ long long omg_dbg_ts[8192][6];   // tools only: per-block timestamps (dbg bit 16): start, stage 0 landed, loop end, epilogue issued, HW_ID, XCC_ID   // tools only: per-wave phase cycle totals of block 0 (dbg bit 16)
 
 namespace {
 
@@ -49,6 +50,8 @@ struct GemmP {
   int Hin, Win, C1, C2, Hout, Wout, ksize, stride, upsample;
   const char* X2;
   int tiles_m, tiles_n;              // tiles_m is per group
+  int stagger_ticks;                 // first-round start delay step in 10 ns ticks (0 = none), see stagger_start()
+  int stagger_groups;
   int dbg;                           // ablation bits (tools only): 1 = no DMA in loop, 2 = no wait/barrier, 4 = no ds_read
 };
 
@@ -343,26 +346,29 @@ template <int N> OMG_DEV void wait_vmcnt() {
 }
 
 // Row-coalesced epilogue shared by the large-tile kernels: one 32-row slab of every wave per pass through a
-// [32][STAGE_LD] fp32 staging area in LDS (bias / per-sample bias / SiLU / GEGLU / residual applied on 16-byte rows).
-template <typename T, int MT>
-OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, int w, int lane, int m0, int n0, int wm, int wn,
+// [32][NT*32 + 4] fp32 staging area in LDS (bias / per-sample bias / SiLU / GEGLU / residual applied on 16-byte rows).
+// The wave's tile is (MT*32) x (NT*32) at (wm0, wn0) = (m0 + wm*MT*32, n0 + wn*NT*32).
+template <typename T, int MT, int NT = 2>
+OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, int w, int lane, int m0, int n0, int wm, int wn,
                             int m_end) {
-  constexpr int NT = 2;
+  constexpr int LD = NT * 32 + 4;                  // 68 (== STAGE_LD) or 132 floats
+  constexpr int LPR = NT * 4;                      // lanes per 16-byte-chunked row (8 or 16)
+  constexpr int RPP = 64 / LPR;                    // rows per pass (8 or 4)
   const int hi = lane >> 5, l31 = lane & 31;
   const int wm0 = m0 + wm * (MT * 32);
-  const int wn0 = n0 + wn * 64;
-  float* stage = (float*)smem + w * (32 * STAGE_LD);
-  const int sub = lane & 7, rsub = lane >> 3;
+  const int wn0 = n0 + wn * (NT * 32);
+  float* stage = (float*)smem + w * (32 * LD);
+  const int sub = lane % LPR, rsub = lane / LPR;
   const int gc = wn0 + sub * 8;
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = 0.f;
   const bool geglu = p.act == OMG_ACT_GEGLU;
   if (!geglu && p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
-#pragma unroll
   // The staging area is private to the wave: LDS executes one wave's instructions in order, so a compiler-level fence
   // between the slab's writes and its reads is all the synchronisation needed (the caller has already joined the block
   // after the K loop).  Block barriers here would re-serialise the two staggered wave groups eight times per tile.
+#pragma unroll
   for (int i = 0; i < MT; ++i) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -371,20 +377,24 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        stage[row * STAGE_LD + j * 32 + l31] = acc[i][j][r];
+        stage[row * LD + j * 32 + l31] = acc[i][j][r];
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (geglu) {
-      const int s4 = lane & 3, r4 = lane >> 2;
+      // every 64-column block is [32 values | 32 gates] (ops.geglu_row_perm): a lane takes 8 values + their 8 gates
+      constexpr int GL = NT * 2;                   // lanes per row (4 or 8)
+      constexpr int GR = 64 / GL;                  // rows per pass (16 or 8)
+      const int s4 = lane % GL, r4 = lane / GL;
+      const int blk = s4 >> 2, c8 = (s4 & 3) * 8;  // 64-column block of the wave tile, value column inside it
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 16 + r4;
+      for (int it = 0; it < 32 / GR; ++it) {
+        const int row = it * GR + r4;
         const int gm = wm0 + i * 32 + row;
-        const int gcc = wn0 + s4 * 8;
+        const int gcc = wn0 + blk * 64 + c8;
         if (gm < m_end && gcc < p.N) {
           float v[8], g[8];
-          const float* sp = stage + row * STAGE_LD + s4 * 8;
+          const float* sp = stage + row * LD + blk * 64 + c8;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
           if (p.bias) {
@@ -397,17 +407,18 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, in
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
-          *(u32x4*)(p.C + ((long)gm * p.ldc + (wn0 >> 1) + s4 * 8) * 2) = pack8<T>(o);
+          const long gms = (p.dbg & 512) ? (gm & 255) : gm;   // tools only: L2-resident destination
+          if (!(p.dbg & 256) || o[0] == 1.2345e-30f) *(u32x4*)(p.C + (gms * p.ldc + ((wn0 + blk * 64) >> 1) + c8) * 2) = pack8<T>(o);
         }
       }
     } else {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + rsub;
+      for (int it = 0; it < 32 / RPP; ++it) {
+        const int row = it * RPP + rsub;
         const int gm = wm0 + i * 32 + row;
         if (gm < m_end && gc < p.N) {
           float v[8];
-          const float* sp = stage + row * STAGE_LD + sub * 8;
+          const float* sp = stage + row * LD + sub * 8;
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
           if (p.group_bias) {
@@ -429,10 +440,205 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][2], char* smem, in
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += rv[e];
           }
-          *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
+          const long gms = (p.dbg & 512) ? (gm & 255) : gm;   // tools only: L2-resident destination
+          if (!(p.dbg & 256) || v[0] == 1.2345e-30f) *(u32x4*)(p.C + (gms * p.ldc + gc) * 2) = pack8<T>(v);
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Register-direct epilogue of the kernels that accumulate the TRANSPOSED tile (v6, v7: mfma(W fragment, A fragment)).
+// Register r of lane (l31, hi) of acc[i][j] is C[wm0 + 32 i + l31][wn0 + 32 j + 8 (r >> 2) + 4 hi + (r & 3)]: a lane owns
+// ONE output row per i and runs of 4 consecutive columns.  v_permlane32_swap trades the second run of a pair with the
+// partner lane (hi ^ 1), after which a lane holds 8 consecutive columns = one 16-byte store; loads of per-column /
+// per-element operands (bias, per-sample bias, residual) go through the same exchange the other way round.
+// No LDS, no barriers: the staging version cost 10-15 us per 256x256 tile (25-35 % of a K=1280 GEMM) — it serialised
+// 32 LDS round trips per wave and waited on vmcnt(0) (which also counts the stores in flight) at every residual load.
+template <typename T>
+OMG_DEV void swap_runs(unsigned (&q)[4]) {   // q[0..1] = run 0 (4 halves), q[2..3] = run 1
+  // v_permlane32_swap v_a, v_b exchanges lanes 32-63 of v_a with lanes 0-31 of v_b (both operands are written).
+  // Inline asm with wait states on both sides, tied to the four registers by data dependence: with the builtin and the
+  // compiler's own hazard nops, lanes 12-15 / 28-31 of each half intermittently saw a stale third dword when the
+  // producer (v_cvt_pk_f16_f32) or the consumer (buffer_store) sat right next to the swap (tools/debug_gemm_small.py).
+  asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 4"
+               : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+}
+// All epilogue memory operations go through buffer descriptors with 32-bit offsets: an offset at or beyond num_records
+// makes a load return zeros and a store vanish, so row / column predicates are a v_cndmask on the offset instead of an
+// exec-mask branch around every access, and there is no 64-bit address arithmetic per access.
+constexpr int EPI_OOB = 0x7f000000;
+OMG_DEV __amdgpu_buffer_rsrc_t epi_rsrc(const char* base, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base != nullptr ? (int)(bytes < 0x7effff00L ? bytes : 0x7effff00L) : 0, 0x00020000);
+}
+// 16 bytes at byte offset `off` (this lane's 8 consecutive columns) -> the 8 values in accumulator order (runs 0, 1)
+template <typename T>
+OMG_DEV void load_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, float (&f)[8]) {
+  const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0);
+  unsigned q[4] = {raw[0], raw[1], raw[2], raw[3]};
+  swap_runs<T>(q);
+  u32x4 sw = {q[0], q[1], q[2], q[3]};
+  unpack8<T>(sw, f);
+}
+template <typename T>
+OMG_DEV void store_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, const float (&f)[8]) {
+  u32x4 pk = pack8<T>(f);
+  unsigned q[4] = {pk[0], pk[1], pk[2], pk[3]};
+  swap_runs<T>(q);
+  u32x4 sw = {q[0], q[1], q[2], q[3]};
+#ifndef OMG_STORE_AUX
+#define OMG_STORE_AUX 0
+#endif
+  // The constant goes into the VGPR offset, never into an SGPR soffset: with `buffer_store_dwordx4 ..., s1 offen` the VALU
+  // instruction right behind the store overwrote dword 2 of the store data in the last lanes of each row before the
+  // store had read it (observed: the next row block's row index in the output; tools/debug_gemm_small.py).  hipcc adds
+  // the wait state only when soffset is an immediate.
+  __builtin_amdgcn_raw_buffer_store_b128(sw, rs, off + soff, 0, OMG_STORE_AUX);
+}
+
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) — the IEEE division of silu_f is ten VALU instructions
+OMG_DEV float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// Accumulators start at the bias instead of zero (one add per output saved in the epilogue, where a wave has no
+// partner to hide VALU latency behind).  Same register <-> element map as epilogue_direct.
+template <typename T, int MT, int NT>
+OMG_DEV bool acc_init_bias(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0) {
+  const int hi = lane >> 5;
+  // the per-sample bias (conv + time embedding) is folded in as well when all rows of the wave tile belong to one sample
+  const bool fold_gb = p.group_bias != nullptr && (wm0 / p.rows_per_group) == ((wm0 + MT * 32 - 1) / p.rows_per_group);
+  const __amdgpu_buffer_rsrc_t rsB = epi_rsrc(p.bias, (long)p.N * 2);
+  const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(fold_gb ? p.group_bias + (long)(wm0 / p.rows_per_group) * p.ldgb * 2 : nullptr, (long)p.N * 2);
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const int c = wn0 + j * 32 + pr * 16 + hi * 8;      // c >= N is beyond num_records: zeros
+      float f[8], g[8];
+      load_runs<T>(rsB, c * 2, 0, f);
+      load_runs<T>(rsG, c * 2, 0, g);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[i][j][pr * 8 + e] = f[e] + g[e];
+    }
+  return p.group_bias != nullptr && !fold_gb;     // true: the epilogue still has to add the per-row group bias
+}
+
+// State shared by the epilogue bodies: descriptors, the lane's column offsets and column predicates.
+template <int NT>
+struct EpiCtx {
+  __amdgpu_buffer_rsrc_t rsC, rsR, rsG;
+  int hi, l31, wm0, m_end;
+  int lane_col;                 // byte offset of the lane's unit (j = 0, pr = 0) inside a row
+  int voob[NT][2];              // 0 where the unit's columns are inside the matrix, EPI_OOB where they are not
+};
+
+// SiLU / per-row group bias / residual decided at run time inside the unit loop: the rare combinations
+template <typename T, int MT, int NT, bool RS, bool GENERIC>
+OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, bool has_gb) {
+  const float osc = p.out_scale;
+  const bool has_rs = GENERIC ? p.residual != nullptr : RS;
+  u32x4 rraw[2][NT][2];         // residual of row block i: the lane's NT*2 16-byte units, fetched one row block ahead
+#define OMG_FETCH_RES(i_, buf_)                                                                            \
+  do {                                                                                                     \
+    const int gm_ = cx.wm0 + (i_) * 32 + cx.l31;                                                           \
+    const int ro_ = gm_ < cx.m_end ? gm_ * (int)p.ldr * 2 + cx.lane_col : EPI_OOB;                         \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
+      _Pragma("unroll") for (int pr = 0; pr < 2; ++pr)                                                     \
+        rraw[buf_][j][pr] = __builtin_amdgcn_raw_buffer_load_b128(cx.rsR, ro_ | cx.voob[j][pr], (j * 32 + pr * 16) * 2, 0); \
+  } while (0)
+  if (has_rs) OMG_FETCH_RES(0, 0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int gm = cx.wm0 + i * 32 + cx.l31;
+    const bool row_ok = gm < cx.m_end;
+    if (has_rs && i + 1 < MT) OMG_FETCH_RES(i + 1, (i + 1) & 1);
+    const int ro = row_ok ? gm * (int)p.ldc * 2 + cx.lane_col : EPI_OOB;
+    const int go = GENERIC && has_gb && row_ok ? ((gm / p.rows_per_group) * (int)p.ldgb) * 2 + cx.lane_col : EPI_OOB;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][j][pr * 8 + e];
+        if constexpr (GENERIC) {
+          if (has_gb) {    // wave tile straddles samples (tiny feature maps only): per-row group bias, latency not hidden
+            float f[8];
+            load_runs<T>(cx.rsG, go | cx.voob[j][pr], (j * 32 + pr * 16) * 2, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += f[e];
+          }
+          if (p.act == OMG_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
+          }
+        }
+        if (has_rs) {
+          const u32x4 rr = rraw[i & 1][j][pr];
+          unsigned q[4] = {rr[0], rr[1], rr[2], rr[3]};
+          swap_runs<T>(q);
+          u32x4 sw = {q[0], q[1], q[2], q[3]};
+          float rf[8];
+          unpack8<T>(sw, rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], osc, rf[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= osc;
+        }
+        store_runs<T>(cx.rsC, ro | cx.voob[j][pr], (j * 32 + pr * 16) * 2, v);
+        __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting every accumulator read to the top (spills)
+      }
+  }
+#undef OMG_FETCH_RES
+}
+
+template <typename T, int MT, int NT>
+OMG_DEV void epilogue_geglu(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, int lane_col_g) {
+  const float osc = p.out_scale;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int gm = cx.wm0 + i * 32 + cx.l31;
+    const int ro = gm < cx.m_end ? gm * (int)p.ldc * 2 + lane_col_g : EPI_OOB;
+#pragma unroll
+    for (int b = 0; b < NT / 2; ++b)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = acc[i][2 * b][pr * 8 + e] * gelu_f(acc[i][2 * b + 1][pr * 8 + e]) * osc;
+        store_runs<T>(cx.rsC, ro | cx.voob[2 * b][pr], (b * 32 + pr * 16) * 2, o);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+}
+
+template <typename T, int MT, int NT>
+OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0, int m_end, bool has_gb) {
+  const bool geglu = p.act == OMG_ACT_GEGLU;
+  const int n_out = geglu ? p.N / 2 : p.N;
+  EpiCtx<NT> cx;
+  cx.hi = lane >> 5; cx.l31 = lane & 31; cx.wm0 = wm0; cx.m_end = m_end;
+  cx.rsC = epi_rsrc(p.C, ((long)(p.M - 1) * p.ldc + n_out) * 2);
+  cx.rsR = epi_rsrc(p.residual, ((long)(p.M - 1) * p.ldr + p.N) * 2);
+  cx.rsG = epi_rsrc(has_gb ? p.group_bias : nullptr, 0x7effff00L);
+  // the buffer bound only protects the end of the matrix, not the end of a row: per-unit column predicate, as an
+  // offset bit pattern that is OR-ed in (row offsets stay far below EPI_OOB's bits)
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) cx.voob[j][pr] = (wn0 + j * 32 + pr * 16 + cx.hi * 8 < p.N && !(p.dbg & 1024)) ? 0 : EPI_OOB;   // dbg 1024 (tools): drop all stores
+  cx.lane_col = (wn0 + cx.hi * 8) * 2;
+  if (geglu) {
+    epilogue_geglu<T, MT, NT>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);   // GEGLU output is half as wide
+  } else if (has_gb || p.act == OMG_ACT_SILU) {
+    epilogue_rows<T, MT, NT, false, true>(p, acc, cx, has_gb);
+  } else if (p.residual != nullptr) {
+    epilogue_rows<T, MT, NT, true, false>(p, acc, cx, false);
+  } else {
+    epilogue_rows<T, MT, NT, false, false>(p, acc, cx, false);
   }
 }
 
@@ -914,6 +1120,20 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
 
+// Desynchronise the CUs of a one-block-per-CU kernel.  All first-round blocks start together and every tile takes the same
+// time, so without this all 256 CUs reach their epilogue at the same moment: 32 MB of C rows hit HBM at once (measured
+// 12-19 us per round at ~2.6 TB/s with the matrix cores idle) and then HBM idles for the whole next main loop.  Delaying
+// group g of the first round by g/G of a tile time puts one group's epilogue under the other groups' main loops for the
+// rest of the launch; later rounds inherit the phase of the CU they land on.
+OMG_DEV void stagger_start(const GemmP& p) {
+  if (p.stagger_ticks <= 0 || (int)blockIdx.x >= 256) return;
+  const int g = ((int)blockIdx.x >> 3) % p.stagger_groups;
+  if (g == 0) return;
+  const unsigned long t0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long wait = (unsigned long)g * (unsigned long)p.stagger_ticks;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+}
+
 // 16 bytes per lane, global -> LDS, through a buffer descriptor.  A non-template wrapper on purpose: with value-dependent
 // arguments the builtin's checks are deferred to instantiation time, where the host pass of hipcc silently drops the kernel.
 OMG_DEV void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
@@ -951,6 +1171,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
   constexpr int A_BYTES = BM_ * BKc * 2;
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
 
+  stagger_start(p);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1025,12 +1246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
 
   const int wm = w / WN_, wn = w % WN_;
   f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * 64);
   using V8 = typename Vec<T>::v8;
   int aro[MT][4], bro[NT][4];
 #pragma unroll
@@ -1093,10 +1309,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
     if constexpr (MT == 4) {                                                                                 \
       _Pragma("unroll") for (int i = ((q_) & 1) * 2; i < ((q_) & 1) * 2 + 2; ++i)                            \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
-          acc[i][j] = Vec<T>::mfma32(af[(q_) >> 1][i], bf[(q_) >> 1][j], acc[i][j]);                         \
+          acc[i][j] = Vec<T>::mfma32(bf[(q_) >> 1][j], af[(q_) >> 1][i], acc[i][j]);                         \
     } else {                                                                                                 \
       _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
-        acc[(q_) & 1][j] = Vec<T>::mfma32(af[(q_) >> 1][(q_) & 1], bf[(q_) >> 1][j], acc[(q_) & 1][j]);      \
+        acc[(q_) & 1][j] = Vec<T>::mfma32(bf[(q_) >> 1][j], af[(q_) >> 1][(q_) & 1], acc[(q_) & 1][j]);      \
     }                                                                                                        \
   } while (0)
 #define OMG_RD(sb_, half_)                                                                                   \
@@ -1159,8 +1375,255 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
 #undef OMG_SO
 #undef OMG_PREP
 #undef OMG_AVO
-  __syncthreads();
-  epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
+  if (p.dbg & 32) {   // tools only: time the tile without its epilogue (the sum keeps the MFMAs alive)
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 1.2345e-30f) p.C[0] = 1;
+    return;
+  }
+  if (p.dbg & 2048) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+  epilogue_direct<T, MT, NT>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * 64, m_end, gb_epi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v7: 256x256x64 tile on FOUR waves (2 x 2), each owning 128x128 of the output (16 accumulator tiles = 256 registers;
+// one wave per SIMD with the whole 512-entry register file).  Per 16-wide k-step a wave reads 4 A + 4 B fragments for 16
+// MFMAs (0.5 ds_read_b128 per MFMA; the 8-wave kernels need 0.75) so the CU's LDS read traffic per stage drops from
+// 192 KB to 128 KB: with the 64 KB of DMA writes, LDS time goes from ~100 % of the MFMA time of a stage to ~75 %.
+// With a single wave per SIMD nothing hides a stall, so the K loop is software-pipelined inside the wave:
+//   * fragments of k-step s+1 are read while the MFMAs of k-step s issue (two fragment register sets);
+//   * the stage's 16 LDS-DMA instructions are spread over two k-steps, one per two MFMAs;
+//   * one block barrier per stage, placed before the LAST k-step: by then every wave has issued (and waited for) its
+//     reads of the current buffer, and the next stage has had two k-steps (~1000 cycles) to land, so right after the
+//     barrier the wave starts reading the next stage's first fragments AND refilling the current buffer with stage kt+2
+//     while the last k-step's MFMAs run.
+template <typename T, bool CONV>
+__global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
+  constexpr int BM_ = 256, BN_ = 256, BKc = 64, MT = 4, NT = 4;
+  constexpr int A_BYTES = BM_ * BKc * 2;
+  constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
+
+  const bool ts_on = (p.dbg & 16) && blockIdx.x < 8192 && threadIdx.x == 0;
+  long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (p.dbg & 16) ts0 = __builtin_amdgcn_s_memrealtime();
+  stagger_start(p);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_per_group = p.tiles_m * p.tiles_n;
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  int tm, tn;
+  {
+    const int per_group = 8 * p.tiles_n;
+    const int gid = t_in / per_group;
+    const int first_m = gid * 8;
+    const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+    const int r = t_in - gid * per_group;
+    tm = first_m + (r % gsz);
+    tn = r / gsz;
+  }
+  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
+  const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
+  const int m0 = m_base + tm * BM_;
+  const int n0 = tn * BN_;
+  int adapter = 0;
+  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
+  if (p.w_adapter_stride != 0 && adapter < 0) return;
+  const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
+  const int nk = (p.K + BKc - 1) / BKc;
+
+  const int Ctot = p.C1 + p.C2;
+  const long a_bytes = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C1 * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(a_bytes < 0x7fffff00 ? a_bytes : 0x7fffff00), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(CONV && p.X2 ? p.X2 : p.A), 0,
+      CONV ? (int)((long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C2 * 2) : 0, 0x00020000);
+  const long w_bytes = ((long)(p.N - 1) * p.ldw + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)w_bytes, 0x00020000);
+
+  // DMA: one instruction moves 8 rows x 128 B; wave w owns row blocks w, w+4, ..., w+28 of A and of W
+  const int prow = lane >> 3, ppos = lane & 7;
+  int voffA[8], voffW[8];
+  int cb[8], cy[8], cx[8];
+  const int dchunk = (ppos ^ ((w & 1) * 4 + (prow >> 1))) * 16;   // ((row >> 1) & 7) with row = (w + 4i) * 8 + prow
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (w + i * 4) * 8 + prow;
+    int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
+    if constexpr (CONV) {
+      const int hw = p.Hout * p.Wout;
+      const int b = gm / hw; const int rem = gm - b * hw;
+      cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;
+      voffA[i] = 0;
+    } else {
+      cb[i] = cy[i] = cx[i] = 0;
+      voffA[i] = (int)((long)gm * p.lda * 2) + dchunk;
+    }
+    int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
+    voffW[i] = (int)((long)gn * p.ldw * 2) + dchunk;
+  }
+  const int ldo = w * 1024;
+
+  const int wm = w >> 1, wn = w & 1;
+  f32x16 acc[MT][NT];
+  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0 + wm * 128, n0 + wn * 128);
+  using V8 = typename Vec<T>::v8;
+  // fragment i of k-step ks sits at aoff[ks] + i * 4096 (32 rows further: same swizzle term)
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int sw = ((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    aoff[ks] = (wm * 128 + l31) * 128 + sw;
+    boff[ks] = A_BYTES + (wn * 128 + l31) * 128 + sw;
+  }
+
+  int koff = 0;
+  int tap_dy = 0, tap_dx = 0, c0b = 0, xCb = 0;
+  bool x2 = false;
+  const int cpt = CONV ? Ctot / BKc : 1;
+  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
+  const int Hl = CONV ? (p.upsample ? p.Hin * 2 : p.Hin) : 0;
+  const int Wl = CONV ? (p.upsample ? p.Win * 2 : p.Win) : 0;
+#define OMG_PREP(kt_)                                                                                      \
+  do {                                                                                                     \
+    koff = (kt_) * (BKc * 2);                                                                              \
+    if constexpr (CONV) {                                                                                  \
+      const int tap = (kt_) / cpt; const int cc = (kt_) - tap * cpt;                                       \
+      tap_dy = tap / p.ksize - pad; tap_dx = tap - (tap / p.ksize) * p.ksize - pad;                        \
+      int c0 = cc * BKc;                                                                                   \
+      x2 = c0 >= p.C1;                                                                                     \
+      if (x2) c0 -= p.C1;                                                                                  \
+      c0b = c0 * 2; xCb = (x2 ? p.C2 : p.C1) * 2;                                                          \
+    }                                                                                                      \
+  } while (0)
+  // DMA instruction d of the prepared stage: d < 8 -> A row block w + 4d, else W row block w + 4(d-8)
+#define OMG_DMA(d_, nb_)                                                                                   \
+  do {                                                                                                     \
+    if ((d_) < 8) {                                                                                        \
+      const int i_ = (d_) & 7;                                                                             \
+      if (CONV) dma16(x2 ? rsA2 : rsA, (nb_) + ldo + i_ * 4096,                                            \
+                      conv_voff(cb[i_], cy[i_], cx[i_], dchunk, p.stride, tap_dy, tap_dx, Hl, Wl, p.upsample, p.Hin, p.Win, xCb, c0b), 0); \
+      else dma16(rsA, (nb_) + ldo + i_ * 4096, voffA[i_], koff);                                           \
+    } else {                                                                                               \
+      const int i_ = (d_) & 7;                                                                             \
+      dma16(rsW, (nb_) + A_BYTES + ldo + i_ * 4096, voffW[i_], koff);                                      \
+    }                                                                                                      \
+  } while (0)
+#define OMG_DMA8(first_, nb_)                                                                              \
+  do { OMG_DMA((first_) + 0, nb_); OMG_DMA((first_) + 1, nb_); OMG_DMA((first_) + 2, nb_); OMG_DMA((first_) + 3, nb_); \
+       OMG_DMA((first_) + 4, nb_); OMG_DMA((first_) + 5, nb_); OMG_DMA((first_) + 6, nb_); OMG_DMA((first_) + 7, nb_); } while (0)
+#define OMG_RD(f_, sb_, ks_)                                                                               \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) bf[f_][j] = *(const V8*)((sb_) + boff[ks_] + j * 4096); \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) af[f_][i] = *(const V8*)((sb_) + aoff[ks_] + i * 4096); \
+  } while (0)
+#define OMG_MM(f_)                                                                                         \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                       \
+        acc[i][j] = Vec<T>::mfma32(af[f_][i], bf[f_][j], acc[i][j]);                                       \
+  } while (0)
+  // one fragment read (r_ < 4: W fragment r_, else A fragment r_-4) / one MFMA (n_ = 4 i + j) / one k-step written in
+  // the issue order wanted: MFMA, read, MFMA, DMA, ... — the compiler keeps LDS-DMA instructions where the source has them
+#define OMG_RD1(f_, sb_, ks_, r_)                                                                          \
+  do {                                                                                                     \
+    if ((r_) < 4) bf[f_][(r_) & 3] = *(const V8*)((sb_) + boff[ks_] + ((r_) & 3) * 4096);                  \
+    else af[f_][(r_) & 3] = *(const V8*)((sb_) + aoff[ks_] + ((r_) & 3) * 4096);                           \
+  } while (0)
+#define OMG_MM1(f_, n_) acc[(n_) >> 2][(n_) & 3] = Vec<T>::mfma32(bf[f_][(n_) & 3], af[f_][(n_) >> 2], acc[(n_) >> 2][(n_) & 3])
+  // k-step computing with fragment set f_ while set 1-f_ is refilled from (rb_, rks_) (RD_ = 1: one read per slot,
+  // 2: two per slot in the first four slots, so that they are back before the loop's first MFMA needs them), and 8 DMAs
+  // (instructions d0_..d0_+7 of the prepared stage into db_) are issued when DMA_
+#define OMG_KSTEP(f_, RD_, rb_, rks_, DMA_, d0_, db_)                                                      \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                     \
+      OMG_MM1(f_, 2 * s_);                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if ((RD_) == 1) OMG_RD1(1 - (f_), rb_, rks_, s_);                                                    \
+      if ((RD_) == 2 && s_ < 4) { OMG_RD1(1 - (f_), rb_, rks_, 2 * s_); OMG_RD1(1 - (f_), rb_, rks_, 2 * s_ + 1); } \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      OMG_MM1(f_, 2 * s_ + 1);                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (DMA_) OMG_DMA((d0_) + s_, db_);                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }                                                                                                      \
+  } while (0)
+
+  V8 af[2][MT], bf[2][NT];
+  // prologue: stage 0 completely, the A half of stage 1, the first fragments
+  OMG_PREP(0);
+  OMG_DMA8(0, smem); OMG_DMA8(8, smem);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (p.dbg & 16) ts1 = __builtin_amdgcn_s_memrealtime();
+  OMG_PREP(1);
+  if (nk > 1) OMG_DMA8(0, smem + STAGE_BYTES);
+  OMG_RD(0, smem, 0);
+
+  // One stage.  HAS1_/HAS2_ (stage kt+1 / kt+2 exist) are literal so that the steady-state body is one basic block —
+  // the interleave requests below only work inside a block; the last two stages are peeled copies.
+#define OMG_STAGE(HAS1_, HAS2_)                                                                            \
+  do {                                                                                                     \
+    const char* cur = smem + (kt & 1) * STAGE_BYTES;                                                       \
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                                       \
+    /* k-step 0 (+ the W half of stage kt+1), k-steps 1, 2 */                                              \
+    OMG_KSTEP(0, 1, cur, 1, HAS1_, 8, nxt);                                                                \
+    OMG_KSTEP(1, 1, cur, 2, false, 0, nxt);                                                                \
+    OMG_KSTEP(0, 1, cur, 3, false, 0, nxt);                                                                \
+    /* stage kt+1 has landed (this wave's part), this wave's reads of `cur` are complete: join the block */ \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    /* k-step 3 (+ first fragments of stage kt+1, + the A half of stage kt+2 into the buffer just released) */ \
+    if (HAS2_) OMG_PREP(kt + 2);                                                                           \
+    OMG_KSTEP(1, (HAS1_) ? 2 : 0, nxt, 0, HAS2_, 0, (char*)cur);                                                     \
+  } while (0)
+  int kt = 0;
+  for (; kt < nk - 2; ++kt) OMG_STAGE(true, true);
+  if (kt < nk - 1) { OMG_STAGE(true, false); ++kt; }
+  OMG_STAGE(false, false);
+#undef OMG_STAGE
+#undef OMG_PREP
+#undef OMG_DMA
+#undef OMG_DMA8
+#undef OMG_RD
+#undef OMG_MM
+#undef OMG_RD1
+#undef OMG_MM1
+#undef OMG_KSTEP
+  if (p.dbg & 32) {   // tools only: time the tile without its epilogue (the sum keeps the MFMAs alive)
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 1.2345e-30f) p.C[0] = 1;
+    return;
+  }
+  if (p.dbg & 16) ts2 = __builtin_amdgcn_s_memrealtime();
+  epilogue_direct<T, MT, NT>(p, acc, lane, m0 + wm * 128, n0 + wn * 128, m_end, gb_epi);
+  if (ts_on) {
+    long long* t = omg_dbg_ts[blockIdx.x];
+    t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID, all 32 bits
+    t[5] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID
+  }
 }
 
 constexpr int lds_bytes_v3(int bm, int bn, int nw, int nst) {
@@ -1211,6 +1674,17 @@ int launch_v5(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v5");
 }
 
+// first-round start delays (stagger_start): G groups, step = tile time / G; us_per_stage is the measured main-loop time
+// of one BK=64 stage of the kernel
+void set_stagger(GemmP& p, int grid, double us_per_stage) {
+  p.stagger_ticks = 0; p.stagger_groups = 1;
+  const int G = (g_dbg & 64) ? 2 : (g_dbg & 128) ? 4 : 0;
+  if (G == 0 || grid <= 256) return;
+  const double tile_us = ((p.K + 63) / 64) * us_per_stage + 3.0;
+  p.stagger_groups = G;
+  p.stagger_ticks = (int)(tile_us * 100.0 / G);
+}
+
 template <typename T, bool CONV, int MT>
 int launch_v6(GemmP p, hipStream_t s, int mrows) {
   constexpr int BN_ = MT == 4 ? 256 : 128;
@@ -1227,8 +1701,29 @@ int launch_v6(GemmP p, hipStream_t s, int mrows) {
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
+  set_stagger(p, grid, MT == 4 ? 1.8 : 1.0);
   OMG_LAUNCH((gemm_kernel_v6<T, CONV, MT>), dim3(grid), dim3(512), lds, s, p);
   return omg_check_launch("gemm_v6");
+}
+
+template <typename T, bool CONV>
+int launch_v7(GemmP p, hipStream_t s, int mrows) {
+  constexpr int ring = 2 * (256 + 256) * 64 * 2;
+  constexpr int epi = 4 * 32 * (4 * 32 + 4) * 4;
+  constexpr int lds = ring > epi ? ring : epi;
+  static bool attr = false;
+  if (!attr) {
+    attr = true;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  p.tiles_m = (mrows + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  p.dbg = g_dbg;
+  const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
+  if (grid <= 0) return OMG_OK;
+  set_stagger(p, grid, 1.7);
+  OMG_LAUNCH((gemm_kernel_v7<T, CONV>), dim3(grid), dim3(256), lds, s, p);
+  return omg_check_launch("gemm_v7");
 }
 
 // Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered BK=64 256x256 kernel (v5) wins whenever it can put
@@ -1257,7 +1752,10 @@ int launch(const GemmP& p, hipStream_t s) {
     // v6 (interleaved DMA) handles everything except the LoRA second K-segment and > 2 GiB operands
     const long lim = 0x7fff0000L;
     const long a_sz = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 : (long)p.M * p.lda * 2;
-    const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim;
+    const long c_sz = (long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) * 2;
+    const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim && c_sz < lim &&
+                      (p.group_bias == nullptr || (long)(p.M / (p.rows_per_group > 0 ? p.rows_per_group : 1) + 1) * p.ldgb * 2 < lim);
+    if (v == 15) { if (v6ok) return launch_v7<T, CONV>(p, s, mrows); v = 11; }
     if (v == 13 || v == 14) { if (v6ok) return v == 13 ? launch_v6<T, CONV, 4>(p, s, mrows) : launch_v6<T, CONV, 2>(p, s, mrows); v = (v == 13) ? 11 : 12; }
     if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
     if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);
@@ -1293,6 +1791,9 @@ void ensure_attrs() {
 
 }  // namespace
 
+extern "C" int omg_debug_read_ts(long long* out, int blocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(omg_dbg_ts), sizeof(long long) * 6 * (blocks < 8192 ? blocks : 8192));
+}
 extern "C" int omg_debug_read_cycles(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(omg_dbg_cycles), sizeof(long long) * 64);
 }

@@ -35,7 +35,7 @@ def main():
     dev, dt = torch.device("cuda:0"), torch.float16
     R = lambda *s: torch.randn(*s, device=dev, dtype=dt)
     lib = L.lib()
-    print("# variants:", variants, " (last column: heuristic)")
+    print("# variants:", variants, " then: heuristic, torch.matmul, [N=1280: heuristic with bias+residual+weight slots]")
     for B in [int(b) for b in a.batches.split(",")]:
         gemms = [(4096, 640, 640, "64^2 proj"), (4096, 1920, 640, "64^2 qkv"), (4096, 5120, 640, "64^2 geglu-w"), (4096, 640, 2560, "64^2 ffout"),
                  (1024, 1280, 1280, "32^2 proj"), (1024, 3840, 1280, "32^2 qkv"), (1024, 10240, 1280, "32^2 geglu-w"), (1024, 1280, 5120, "32^2 ffout")]
@@ -47,6 +47,17 @@ def main():
             for v in variants + [0]:
                 lib.omg_debug_set_gemm_variant(v)
                 ms = timeit(lambda: ops.gemm(x, w, out=out, groups=B if a.grouped else 1))
+                row.append(2 * M * N * K / ms / 1e9)
+            # the same product through torch.matmul (hipBLASLt / rocBLAS): a library reference point, not a product path
+            wt = w.t()
+            ms = timeit(lambda: torch.matmul(x, wt, out=out))
+            row.append(2 * M * N * K / ms / 1e9)
+            if N == 1280:   # in-situ form of to_out: bias + residual + per-sample weight slots
+                lib.omg_debug_set_gemm_variant(0)
+                ws = torch.stack([w, w, w]).contiguous()
+                ga = (torch.arange(B, device=dev) % 3).to(torch.int32)
+                bias, res = R(N), R(M, N)
+                ms = timeit(lambda: ops.gemm(x, ws, bias=bias, residual=res, out=out, groups=B, w_group_adapter=ga))
                 row.append(2 * M * N * K / ms / 1e9)
             print(f"gemm B{B:<2d} {tag:14s} M={M:6d} N={N:5d} K={K:5d}: " + " ".join(f"{r:7.0f}" for r in row))
         convs = [(128, 320, 0, 320, 1, 0, "128^2 320"), (128, 320, 0, 320, 2, 0, "128^2 320 s2"), (64, 320, 0, 640, 1, 0, "64^2 320->640"),
