@@ -44,6 +44,8 @@ template <typename T> OMG_DEV u32x4 pack8(const float (&f)[8]) {
 }
 
 OMG_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) — the IEEE division of silu_f is ten VALU instructions (GEMM epilogues)
+OMG_DEV float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) GELU — diffusers GEGLU uses F.gelu(gate) with the default approximate='none'.
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the half-precision rounding of the result), branch-free:
 // ~14 VALU instructions instead of libm's two-branch erff, which made the GEGLU epilogue as long as five K-steps of MFMA.

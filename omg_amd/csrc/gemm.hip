@@ -67,6 +67,34 @@ OMG_DEV void stage16(const char* src, char* lds_wave_base, int lane, u32x4& hold
   }
 }
 
+// Every GEMM/conv variant produces the same bits for the same problem (so that batching requests, which changes the
+// tile choice, does not change results): accumulators start at bias (+ the per-sample bias when a sample's rows are a
+// multiple of 256, i.e. no tile of any variant straddles samples), the K loop adds the products in the same order, and
+// the epilogue is [+ per-row group bias if it was not folded] -> SiLU (hardware reciprocal) -> fma(v, out_scale, residual).
+OMG_DEV bool fold_group_bias(const GemmP& p) { return p.group_bias != nullptr && p.rows_per_group % 256 == 0; }
+
+// non-transposed accumulators: acc[i][j][r] is column col0 + 32 j + l31
+template <typename T, int MT, int NT>
+OMG_DEV void acc_init_cols(const GemmP& p, f32x16 (&acc)[MT][NT], int l31, int col0, int m0) {
+  const bool fold = fold_group_bias(p);
+  const long grow = fold ? (long)(m0 / p.rows_per_group) * p.ldgb : 0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int c = col0 + j * 32 + l31;
+    float b = 0.f;
+    if (c < p.N) {
+      float g = 0.f;
+      if (p.bias) b = (float)((const T*)p.bias)[c];
+      if (fold) g = (float)((const T*)p.group_bias)[grow + c];
+      b = b + g;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+  }
+}
+
 template <typename T>
 OMG_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], char* smem, int w, int lane, int m0, int n0, int m_end) {
   const int hi = lane >> 5, l31 = lane & 31;
@@ -97,16 +125,10 @@ OMG_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], char* smem, int 
       const int gm = wm0 + row;
       const int gc = wn0 + sub * 8;          // packed column of the value half
       if (gm < m_end && gc < p.N) {
-        float v[8], g[8], bv[8], bg[8];
+        float v[8], g[8];
         const float* sp = stage + row * STAGE_LD + sub * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
-        if (p.bias) {
-          unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
-          unpack8<T>(*(const u32x4*)(p.bias + (long)(gc + 32) * 2), bg);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { v[e] += bv[e]; g[e] += bg[e]; }
-        }
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
@@ -118,10 +140,7 @@ OMG_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], char* smem, int 
   {
     const int sub = lane & 7, rsub = lane >> 3;
     const int gc = wn0 + sub * 8;
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-    if (p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+    const bool gb_rows = p.group_bias != nullptr && !fold_group_bias(p);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + rsub;
@@ -130,8 +149,8 @@ OMG_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], char* smem, int 
         float v[8];
         const float* sp = stage + row * STAGE_LD + sub * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
-        if (p.group_bias) {
+        for (int e = 0; e < 8; ++e) v[e] = sp[e];
+        if (gb_rows) {
           float gb[8];
           const int g = gm / p.rows_per_group;
           unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
@@ -140,15 +159,16 @@ OMG_DEV void gemm_epilogue(const GemmP& p, f32x16 (&acc)[2][2], char* smem, int 
         }
         if (p.act == OMG_ACT_SILU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
         if (p.residual) {
           float rv[8];
           unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
+          for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], p.out_scale, rv[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
         }
         *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
       }
@@ -285,12 +305,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 
   const int wm = w >> 1, wn = w & 1;
   f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init_cols<T, 2, 2>(p, acc, lane & 31, n0 + wn * 64, m0);
 
   using V8 = typename Vec<T>::v8;
 
@@ -360,11 +375,8 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
   float* stage = (float*)smem + w * (32 * LD);
   const int sub = lane % LPR, rsub = lane / LPR;
   const int gc = wn0 + sub * 8;
-  float bv[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bv[e] = 0.f;
   const bool geglu = p.act == OMG_ACT_GEGLU;
-  if (!geglu && p.bias && gc < p.N) unpack8<T>(*(const u32x4*)(p.bias + (long)gc * 2), bv);
+  const bool gb_rows = p.group_bias != nullptr && !fold_group_bias(p);
   // The staging area is private to the wave: LDS executes one wave's instructions in order, so a compiler-level fence
   // between the slab's writes and its reads is all the synchronisation needed (the caller has already joined the block
   // after the K loop).  Block barriers here would re-serialise the two staggered wave groups eight times per tile.
@@ -397,13 +409,6 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
           const float* sp = stage + row * LD + blk * 64 + c8;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
-          if (p.bias) {
-            float b1[8], b2[8];
-            unpack8<T>(*(const u32x4*)(p.bias + (long)gcc * 2), b1);
-            unpack8<T>(*(const u32x4*)(p.bias + (long)(gcc + 32) * 2), b2);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v[e] += b1[e]; g[e] += b2[e]; }
-          }
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
@@ -420,8 +425,8 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
           float v[8];
           const float* sp = stage + row * LD + sub * 8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = sp[e] + bv[e];
-          if (p.group_bias) {
+          for (int e = 0; e < 8; ++e) v[e] = sp[e];
+          if (gb_rows) {
             float gb[8];
             const int g = gm / p.rows_per_group;
             unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
@@ -430,15 +435,16 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
           }
           if (p.act == OMG_ACT_SILU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+            for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
           }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
           if (p.residual) {
             float rv[8];
             unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], p.out_scale, rv[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
           }
           const long gms = (p.dbg & 512) ? (gm & 255) : gm;   // tools only: L2-resident destination
           if (!(p.dbg & 256) || v[0] == 1.2345e-30f) *(u32x4*)(p.C + (gms * p.ldc + gc) * 2) = pack8<T>(v);
@@ -497,18 +503,15 @@ OMG_DEV void store_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, const floa
   __builtin_amdgcn_raw_buffer_store_b128(sw, rs, off + soff, 0, OMG_STORE_AUX);
 }
 
-// x * sigmoid(x) with the hardware reciprocal (1 ulp) — the IEEE division of silu_f is ten VALU instructions
-OMG_DEV float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
 // Accumulators start at the bias instead of zero (one add per output saved in the epilogue, where a wave has no
 // partner to hide VALU latency behind).  Same register <-> element map as epilogue_direct.
 template <typename T, int MT, int NT>
-OMG_DEV bool acc_init_bias(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0) {
+OMG_DEV bool acc_init_bias(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int m0, int wn0) {
   const int hi = lane >> 5;
-  // the per-sample bias (conv + time embedding) is folded in as well when all rows of the wave tile belong to one sample
-  const bool fold_gb = p.group_bias != nullptr && (wm0 / p.rows_per_group) == ((wm0 + MT * 32 - 1) / p.rows_per_group);
+  // the per-sample bias (conv + time embedding) is folded in as well under the rule shared by all variants
+  const bool fold_gb = fold_group_bias(p);
   const __amdgpu_buffer_rsrc_t rsB = epi_rsrc(p.bias, (long)p.N * 2);
-  const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(fold_gb ? p.group_bias + (long)(wm0 / p.rows_per_group) * p.ldgb * 2 : nullptr, (long)p.N * 2);
+  const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(fold_gb ? p.group_bias + (long)(m0 / p.rows_per_group) * p.ldgb * 2 : nullptr, (long)p.N * 2);
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -787,12 +790,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
 
   const int wm = w / WN_, wn = w % WN_;
   f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init_cols<T, MT, NT>(p, acc, lane & 31, n0 + wn * (NT * 32), m0);
   using V8 = typename Vec<T>::v8;
 
   // stage-relative fragment offsets (ks = 0/1 differ by chunk ^ 2 -> precompute both)
@@ -1054,12 +1052,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
 
   const int wm = w / WN_, wn = w % WN_;
   f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  acc_init_cols<T, MT, NT>(p, acc, lane & 31, n0 + wn * (NT * 32), m0);
   using V8 = typename Vec<T>::v8;
 
   // stage-relative fragment offsets (ks = 0/1 differ by chunk ^ 2 -> precompute both)
@@ -1246,7 +1239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
 
   const int wm = w / WN_, wn = w % WN_;
   f32x16 acc[MT][NT];
-  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * 64);
+  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * 64);
   using V8 = typename Vec<T>::v8;
   int aro[MT][4], bro[NT][4];
 #pragma unroll
@@ -1481,7 +1474,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 
   const int wm = w >> 1, wn = w & 1;
   f32x16 acc[MT][NT];
-  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0 + wm * 128, n0 + wn * 128);
+  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * 128);
   using V8 = typename Vec<T>::v8;
   // fragment i of k-step ks sits at aoff[ks] + i * 4096 (32 rows further: same swizzle term)
   int aoff[4], boff[4];
@@ -1737,7 +1730,7 @@ int choose_variant(int mrows, int groups, int N) {
   // the narrow tile wins when N pads badly to 256 (320 -> 512) or its tile count fills the last round better
   const double c256 = (double)((t256 + 255) / 256);
   const double c128 = (double)((t256x128 + 255) / 256) * 0.58;
-  if (N > 128 && t256 >= 120 && c256 <= c128 * 1.06) return 13;   // 256x256, BK=64 double buffer, staggered, interleaved DMA
+  if (N > 128 && t256 >= 120 && c256 <= c128 * 1.06) return 15;   // 256x256 on four waves (v7); 13 = the eight-wave v6 of the same tile
   if (t256x128 >= 120) return 14;                                  // 256x128, same structure
   return 1;
 }

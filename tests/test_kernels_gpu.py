@@ -280,3 +280,39 @@ def test_timestep_embedding_and_silu(dev, dtype):
     dst = torch.zeros(7, 100, dtype=dtype, device=dev)
     ops.copy2d(src, dst[:, 16:56])
     assert torch.equal(dst[:, 16:56], src) and dst[:, :16].abs().sum() == 0
+
+
+# ------------------------------------------------------------------ every tile variant gives the same bits
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_variants_are_bitwise_identical(dev, dtype):
+    """Batching requests changes the tile choice; results must not change with it (bias-first accumulation, same K order,
+    same epilogue arithmetic in every kernel — see fold_group_bias in csrc/gemm.hip)."""
+    lib = L.lib()
+    M, N, K = 600, 704, 320
+    a = rnd(M, K, dtype=dtype, dev=dev)
+    w = rnd(N, K, dtype=dtype, dev=dev, scale=K ** -0.5)
+    b = rnd(N, dtype=dtype, dev=dev)
+    res = rnd(M, N, dtype=dtype, dev=dev)
+    gb = rnd(3, N, dtype=dtype, dev=dev)
+    perm = ops.geglu_row_perm(N).to(dev)
+    wg, bg = w[perm].contiguous(), b[perm].contiguous()
+    x = rnd(2, 16, 16, 128, dtype=dtype, dev=dev)                  # conv: rows per sample = 256 -> group bias folded
+    x8 = rnd(6, 8, 8, 128, dtype=dtype, dev=dev)                   # rows per sample = 64 -> per-row group bias
+    wc = rnd(192, 9 * 128, dtype=dtype, dev=dev, scale=(9 * 128) ** -0.5)
+    bc = rnd(192, dtype=dtype, dev=dev)
+    gbc, gbc8 = rnd(2, 192, dtype=dtype, dev=dev), rnd(6, 192, dtype=dtype, dev=dev)
+
+    def run_all():
+        return [ops.gemm(a, w, bias=b), ops.gemm(a, w, bias=b, residual=res, out_scale=0.5), ops.gemm(a, wg, bias=bg, act=L.ACT_GEGLU),
+                ops.gemm(a, w, bias=b, group_bias=gb, groups=3), ops.conv2d(x, wc, 3, bias=bc, group_bias=gbc),
+                ops.conv2d(x8, wc, 3, bias=bc, group_bias=gbc8, act=L.ACT_SILU)]
+
+    try:
+        lib.omg_debug_set_gemm_variant(1)
+        base = run_all()
+        for v in (11, 12, 13, 14, 15):
+            lib.omg_debug_set_gemm_variant(v)
+            for k, (o, r) in enumerate(zip(run_all(), base)):
+                assert torch.equal(o, r), f"variant {v} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
+    finally:
+        lib.omg_debug_set_gemm_variant(0)

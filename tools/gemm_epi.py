@@ -29,12 +29,12 @@ def timeit(fn, iters=20, warm=5):
 for v in (13, 15):
     for name, kw in (("plain", {}), ("bias+res", dict(bias=b, residual=res)), ("geglu", dict(bias=b, act=L.ACT_GEGLU))):
         row = []
-        for dbg in (0, 32, 256, 128):
+        for dbg in (0, 32, 64, 128):
             L.lib().omg_debug_set_gemm_variant(v | (dbg << 8))
             row.append(timeit(lambda: ops.gemm(x, w, **kw)))
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
         rounds = (tiles + 255) // 256
-        print(f"variant {v} {name:9s}: {row[0]*1e3:8.1f} us ({2*M*N*K/row[0]/1e9:6.0f} TF/s)   nt-store {row[2]*1e3:8.1f} us ({2*M*N*K/row[2]/1e9:6.0f})  stagger4 {row[3]*1e3:8.1f} us ({2*M*N*K/row[3]/1e9:6.0f})   no-epilogue {row[1]*1e3:8.1f} us ({2*M*N*K/row[1]/1e9:6.0f} TF/s)"
+        print(f"variant {v} {name:9s}: {row[0]*1e3:8.1f} us ({2*M*N*K/row[0]/1e9:6.0f} TF/s)   stagger2 {row[2]*1e3:8.1f} us ({2*M*N*K/row[2]/1e9:6.0f})  stagger4 {row[3]*1e3:8.1f} us ({2*M*N*K/row[3]/1e9:6.0f})   no-epilogue {row[1]*1e3:8.1f} us ({2*M*N*K/row[1]/1e9:6.0f} TF/s)"
               f"   epilogue/tile-round {(row[0]-row[1])*1e3/rounds:6.2f} us of {row[0]*1e3/rounds:6.2f} us  ({tiles} tiles, {rounds} rounds)")
 L.lib().omg_debug_set_gemm_variant(0)
 # HBM write / copy ceilings for scale
