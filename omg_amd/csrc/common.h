@@ -20,10 +20,12 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct Vec;
 template <> struct Vec<f16> {
   using v8 = f16x8; using v4 = f16x4;
+  static constexpr bool is_f16 = true;
   static OMG_DEV f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Vec<bf16> {
   using v8 = bf16x8; using v4 = bf16x4;
+  static constexpr bool is_f16 = false;
   static OMG_DEV f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 

@@ -1395,7 +1395,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
 //     reads of the current buffer, and the next stage has had two k-steps (~1000 cycles) to land, so right after the
 //     barrier the wave starts reading the next stage's first fragments AND refilling the current buffer with stage kt+2
 //     while the last k-step's MFMAs run.
-template <typename T, bool CONV>
+// ABL (tools only, results are wrong): 1 = no LDS-DMA in the K loop, 2 = no fragment reads in the K loop, 4 = no wait / barrier
+template <typename T, bool CONV, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   constexpr int BM_ = 256, BN_ = 256, BKc = 64, MT = 4, NT = 4;
   constexpr int A_BYTES = BM_ * BKc * 2;
@@ -1535,8 +1536,11 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   // the issue order wanted: MFMA, read, MFMA, DMA, ... — the compiler keeps LDS-DMA instructions where the source has them
 #define OMG_RD1(f_, sb_, ks_, r_)                                                                          \
   do {                                                                                                     \
-    if ((r_) < 4) bf[f_][(r_) & 3] = *(const V8*)((sb_) + boff[ks_] + ((r_) & 3) * 4096);                  \
-    else af[f_][(r_) & 3] = *(const V8*)((sb_) + aoff[ks_] + ((r_) & 3) * 4096);                           \
+    /* read order = order of first use by the MFMAs (n = 4 i + j): W0, A0, W1, W2, W3, A1, A2, A3 */       \
+    const bool isA_ = (r_) == 1 || (r_) >= 5;                                                              \
+    const int idx_ = (r_) == 0 ? 0 : (r_) == 1 ? 0 : (r_) <= 4 ? (r_) - 1 : (r_) - 4;                      \
+    if (!isA_) bf[f_][idx_] = *(const V8*)((sb_) + boff[ks_] + idx_ * 4096);                               \
+    else af[f_][idx_] = *(const V8*)((sb_) + aoff[ks_] + idx_ * 4096);                                     \
   } while (0)
 #define OMG_MM1(f_, n_) acc[(n_) >> 2][(n_) & 3] = Vec<T>::mfma32(bf[f_][(n_) & 3], af[f_][(n_) >> 2], acc[(n_) >> 2][(n_) & 3])
   // k-step computing with fragment set f_ while set 1-f_ is refilled from (rb_, rks_) (RD_ = 1: one read per slot,
@@ -1547,12 +1551,12 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                     \
       OMG_MM1(f_, 2 * s_);                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if ((RD_) == 1) OMG_RD1(1 - (f_), rb_, rks_, s_);                                                    \
-      if ((RD_) == 2 && s_ < 4) { OMG_RD1(1 - (f_), rb_, rks_, 2 * s_); OMG_RD1(1 - (f_), rb_, rks_, 2 * s_ + 1); } \
+      if ((RD_) == 1 && !(ABL & 2)) OMG_RD1(1 - (f_), rb_, rks_, s_);                                                    \
+      if ((RD_) == 2 && s_ < 4 && !(ABL & 2)) { OMG_RD1(1 - (f_), rb_, rks_, 2 * s_); OMG_RD1(1 - (f_), rb_, rks_, 2 * s_ + 1); } \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       OMG_MM1(f_, 2 * s_ + 1);                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if (DMA_) OMG_DMA((d0_) + s_, db_);                                                                  \
+      if ((DMA_) && !(ABL & 1)) OMG_DMA((d0_) + s_, db_);                                                                  \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
     }                                                                                                      \
   } while (0)
@@ -1579,8 +1583,8 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
     OMG_KSTEP(1, 1, cur, 2, false, 0, nxt);                                                                \
     OMG_KSTEP(0, 1, cur, 3, false, 0, nxt);                                                                \
     /* stage kt+1 has landed (this wave's part), this wave's reads of `cur` are complete: join the block */ \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
-    __builtin_amdgcn_s_barrier();                                                                          \
+    if (!(ABL & 4)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } \
+    /* */                                                                                                  \
     /* k-step 3 (+ first fragments of stage kt+1, + the A half of stage kt+2 into the buffer just released) */ \
     if (HAS2_) OMG_PREP(kt + 2);                                                                           \
     OMG_KSTEP(1, (HAS1_) ? 2 : 0, nxt, 0, HAS2_, 0, (char*)cur);                                                     \
@@ -1699,7 +1703,7 @@ int launch_v6(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v6");
 }
 
-template <typename T, bool CONV>
+template <typename T, bool CONV, int ABL = 0>
 int launch_v7(GemmP p, hipStream_t s, int mrows) {
   constexpr int ring = 2 * (256 + 256) * 64 * 2;
   constexpr int epi = 4 * 32 * (4 * 32 + 4) * 4;
@@ -1707,7 +1711,7 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<T, CONV, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
@@ -1715,7 +1719,7 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
   set_stagger(p, grid, 1.7);
-  OMG_LAUNCH((gemm_kernel_v7<T, CONV>), dim3(grid), dim3(256), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v7<T, CONV, ABL>), dim3(grid), dim3(256), lds, s, p);
   return omg_check_launch("gemm_v7");
 }
 
@@ -1749,6 +1753,19 @@ int launch(const GemmP& p, hipStream_t s) {
     const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim && c_sz < lim &&
                       (p.group_bias == nullptr || (long)(p.M / (p.rows_per_group > 0 ? p.rows_per_group : 1) + 1) * p.ldgb * 2 < lim);
     if (v == 15) { if (v6ok) return launch_v7<T, CONV>(p, s, mrows); v = 11; }
+    if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
+      if (v >= 17 && v <= 23 && v6ok) {
+        switch (v - 16) {
+          case 1: return launch_v7<T, CONV, 1>(p, s, mrows);
+          case 2: return launch_v7<T, CONV, 2>(p, s, mrows);
+          case 3: return launch_v7<T, CONV, 3>(p, s, mrows);
+          case 4: return launch_v7<T, CONV, 4>(p, s, mrows);
+          case 5: return launch_v7<T, CONV, 5>(p, s, mrows);
+          case 6: return launch_v7<T, CONV, 6>(p, s, mrows);
+          default: return launch_v7<T, CONV, 7>(p, s, mrows);
+        }
+      }
+    }
     if (v == 13 || v == 14) { if (v6ok) return v == 13 ? launch_v6<T, CONV, 4>(p, s, mrows) : launch_v6<T, CONV, 2>(p, s, mrows); v = (v == 13) ? 11 : 12; }
     if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
     if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);
