@@ -173,7 +173,7 @@ def main():
         g_ms, g_fl, g_n = comb("gemm", "ms"), comb("gemm", "flops"), comb("gemm", "launches")
         a_ms, a_fl = comb("attn", "ms"), comb("attn", "flops")
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)",
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_v7 / gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)",
                            "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": None,
                            "launches_per_step": g_n, "avg_launch_us": 1e3 * g_ms / g_n, "avg_launch_gflop": g_fl / g_n / 1e9,
                            "gemm_ms_per_step": g_ms,
