@@ -1623,6 +1623,225 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v8: v7 made persistent.  One block per CU walks tiles t = blockIdx.x, + gridDim.x, ... (same tile -> XCD map as the
+// one-block-per-tile launch).  After the K loop of a tile — once past the last stage barrier nobody reads LDS any
+// more — the wave sets up the NEXT tile and issues its first TWO stages (32 LDS-DMA instructions) before it starts the
+// epilogue of the current tile: the 3.8 us prologue (first-stage latency) and the 0.6 us block hand-over of v7 disappear
+// under the 5.6 us epilogue, and the loads are ahead of the epilogue's 128 KB of stores in the CU's memory pipeline.
+// Same arithmetic, same bits as every other variant.
+template <typename T, bool CONV>
+__global__ __launch_bounds__(256, 1) void gemm_kernel_v8(GemmP p) {
+  constexpr int BM_ = 256, BN_ = 256, BKc = 64, MT = 4, NT = 4;
+  constexpr int A_BYTES = BM_ * BKc * 2;
+  constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+
+  const int tiles_per_group = p.tiles_m * p.tiles_n;
+  const int total = p.tile_groups * tiles_per_group;
+  const int nk = (p.K + BKc - 1) / BKc;
+  const int Ctot = p.C1 + p.C2;
+  const long a_bytes = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C1 * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(a_bytes < 0x7fffff00 ? a_bytes : 0x7fffff00), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(CONV && p.X2 ? p.X2 : p.A), 0,
+      CONV ? (int)((long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C2 * 2) : 0, 0x00020000);
+  const long w_bytes = ((long)(p.N - 1) * p.ldw + p.K) * 2;
+
+  const int prow = lane >> 3, ppos = lane & 7;
+  const int dchunk = (ppos ^ ((w & 1) * 4 + (prow >> 1))) * 16;
+  const int ldo = w * 1024;
+  const int wm = w >> 1, wn = w & 1;
+  using V8 = typename Vec<T>::v8;
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int sw = ((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+    aoff[ks] = (wm * 128 + l31) * 128 + sw;
+    boff[ks] = A_BYTES + (wn * 128 + l31) * 128 + sw;
+  }
+  int koff = 0;
+  int tap_dy = 0, tap_dx = 0, c0b = 0, xCb = 0;
+  bool x2 = false;
+  const int cpt = CONV ? Ctot / BKc : 1;
+  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
+  const int Hl = CONV ? (p.upsample ? p.Hin * 2 : p.Hin) : 0;
+  const int Wl = CONV ? (p.upsample ? p.Win * 2 : p.Win) : 0;
+
+  // ---- state of the tile whose loads are being issued
+  int m0 = 0, n0 = 0, m_end = 0, tile = 0;
+  bool more = false;
+  __amdgpu_buffer_rsrc_t rsW = rsA;
+  // Plain GEMM: row block i of a wave is 32 rows further (no clamping: rows past the matrix end are out of the buffer's
+  // range and read as zeros, rows of the next group only feed accumulator rows the epilogue never stores), so one VGPR
+  // offset per operand plus an SGPR step replaces the 16 per-tile offsets of v7; the conv keeps its pixel coordinates.
+  int voffA0 = 0, voffW0 = 0;
+  const int stepA = CONV ? 0 : (int)(32 * p.lda * 2), stepW = (int)(32 * p.ldw * 2);
+  int cb[8], cy[8], cx[8];
+  // first tile >= t_ (stepping by the grid) whose group has a weight slot; `more` says whether there is one
+#define OMG_TILE(t_)                                                                                       \
+  do {                                                                                                     \
+   tile = (t_);                                                                                            \
+   for (;;) {                                                                                              \
+    more = tile < total;                                                                                   \
+    if (!more) break;                                                                                      \
+    int bid_;                                                                                              \
+    {                                                                                                      \
+      const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3;                              \
+      bid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                \
+    }                                                                                                      \
+    const int grp = bid_ / tiles_per_group;                                                                \
+    const int t_in = bid_ - grp * tiles_per_group;                                                         \
+    int tm, tn;                                                                                            \
+    {                                                                                                      \
+      const int per_group = 8 * p.tiles_n;                                                                 \
+      const int gid = t_in / per_group;                                                                    \
+      const int first_m = gid * 8;                                                                         \
+      const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;                               \
+      const int r = t_in - gid * per_group;                                                                \
+      tm = first_m + (r % gsz);                                                                            \
+      tn = r / gsz;                                                                                        \
+    }                                                                                                      \
+    const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;                                   \
+    m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;                                         \
+    m0 = m_base + tm * BM_;                                                                                \
+    n0 = tn * BN_;                                                                                         \
+    int adapter = 0;                                                                                       \
+    if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];                                        \
+    if (p.w_adapter_stride != 0 && adapter < 0) { tile += (int)gridDim.x; continue; }                      \
+    const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);         \
+    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)w_bytes, 0x00020000);                       \
+    {                                                                                                      \
+      const int r0 = w * 8 + prow;                                                                         \
+      voffW0 = (int)((long)(n0 + r0) * p.ldw * 2) + dchunk;                                                \
+      if constexpr (!CONV) voffA0 = (int)((long)(m0 + r0) * p.lda * 2) + dchunk;                           \
+    }                                                                                                      \
+    if constexpr (CONV) {                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                      \
+        const int r = (w + i * 4) * 8 + prow;                                                              \
+        int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;                                               \
+        const int hw = p.Hout * p.Wout;                                                                    \
+        const int b = gm / hw; const int rem = gm - b * hw;                                                \
+        cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;                                     \
+      }                                                                                                    \
+    }                                                                                                      \
+    break;                                                                                                 \
+   }                                                                                                       \
+  } while (0)
+#define OMG_PREP(kt_)                                                                                      \
+  do {                                                                                                     \
+    koff = (kt_) * (BKc * 2);                                                                              \
+    if constexpr (CONV) {                                                                                  \
+      const int tap = (kt_) / cpt; const int cc = (kt_) - tap * cpt;                                       \
+      tap_dy = tap / p.ksize - pad; tap_dx = tap - (tap / p.ksize) * p.ksize - pad;                        \
+      int c0 = cc * BKc;                                                                                   \
+      x2 = c0 >= p.C1;                                                                                     \
+      if (x2) c0 -= p.C1;                                                                                  \
+      c0b = c0 * 2; xCb = (x2 ? p.C2 : p.C1) * 2;                                                          \
+    }                                                                                                      \
+  } while (0)
+#define OMG_DMA(d_, nb_)                                                                                   \
+  do {                                                                                                     \
+    if ((d_) < 8) {                                                                                        \
+      const int i_ = (d_) & 7;                                                                             \
+      if (CONV) dma16(x2 ? rsA2 : rsA, (nb_) + ldo + i_ * 4096,                                            \
+                      conv_voff(cb[i_], cy[i_], cx[i_], dchunk, p.stride, tap_dy, tap_dx, Hl, Wl, p.upsample, p.Hin, p.Win, xCb, c0b), 0); \
+      else dma16(rsA, (nb_) + ldo + i_ * 4096, voffA0, koff + i_ * stepA);                                         \
+    } else {                                                                                               \
+      const int i_ = (d_) & 7;                                                                             \
+      dma16(rsW, (nb_) + A_BYTES + ldo + i_ * 4096, voffW0, koff + i_ * stepW);                                      \
+    }                                                                                                      \
+  } while (0)
+#define OMG_DMA16(nb_)                                                                                     \
+  do { _Pragma("unroll") for (int d_ = 0; d_ < 16; ++d_) OMG_DMA(d_, nb_); } while (0)
+  // first two stages of the tile just set up (both LDS buffers are free)
+#define OMG_PROLOGUE()                                                                                     \
+  do {                                                                                                     \
+    OMG_PREP(0); OMG_DMA16(smem);                                                                          \
+    if (nk > 1) { OMG_PREP(1); OMG_DMA16(smem + STAGE_BYTES); }                                            \
+  } while (0)
+#define OMG_RD(f_, sb_, ks_)                                                                               \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) bf[f_][j] = *(const V8*)((sb_) + boff[ks_] + j * 4096); \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) af[f_][i] = *(const V8*)((sb_) + aoff[ks_] + i * 4096); \
+  } while (0)
+#define OMG_RD1(f_, sb_, ks_, r_)                                                                          \
+  do {                                                                                                     \
+    const bool isA_ = (r_) == 1 || (r_) >= 5;                                                              \
+    const int idx_ = (r_) == 0 ? 0 : (r_) == 1 ? 0 : (r_) <= 4 ? (r_) - 1 : (r_) - 4;                      \
+    if (!isA_) bf[f_][idx_] = *(const V8*)((sb_) + boff[ks_] + idx_ * 4096);                               \
+    else af[f_][idx_] = *(const V8*)((sb_) + aoff[ks_] + idx_ * 4096);                                     \
+  } while (0)
+#define OMG_MM1(f_, n_) acc[(n_) >> 2][(n_) & 3] = Vec<T>::mfma32(bf[f_][(n_) & 3], af[f_][(n_) >> 2], acc[(n_) >> 2][(n_) & 3])
+#define OMG_KSTEP(f_, RD_, rb_, rks_, DMA_, d0_, db_)                                                      \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                     \
+      OMG_MM1(f_, 2 * s_);                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if ((RD_) == 1) OMG_RD1(1 - (f_), rb_, rks_, s_);                                                    \
+      if ((RD_) == 2 && s_ < 4) { OMG_RD1(1 - (f_), rb_, rks_, 2 * s_); OMG_RD1(1 - (f_), rb_, rks_, 2 * s_ + 1); } \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      OMG_MM1(f_, 2 * s_ + 1);                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (DMA_) OMG_DMA((d0_) + s_, db_);                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }                                                                                                      \
+  } while (0)
+  // one stage (see v7); W0_ = false for the first stage of a tile, whose successor was loaded whole by the prologue
+#define OMG_STAGE(HAS1_, HAS2_, W0_)                                                                       \
+  do {                                                                                                     \
+    const char* cur = smem + (kt & 1) * STAGE_BYTES;                                                       \
+    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                                       \
+    OMG_KSTEP(0, 1, cur, 1, (HAS1_) && (W0_), 8, nxt);                                                     \
+    OMG_KSTEP(1, 1, cur, 2, false, 0, nxt);                                                                \
+    OMG_KSTEP(0, 1, cur, 3, false, 0, nxt);                                                                \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
+    __builtin_amdgcn_s_barrier();                                                                          \
+    if (HAS2_) OMG_PREP(kt + 2);                                                                           \
+    OMG_KSTEP(1, (HAS1_) ? 2 : 0, nxt, 0, HAS2_, 0, (char*)cur);                                           \
+  } while (0)
+
+  f32x16 acc[MT][NT];
+  V8 af[2][MT], bf[2][NT];
+  OMG_TILE((int)blockIdx.x);
+  if (!more) return;
+  OMG_PROLOGUE();
+  for (;;) {
+    const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * 128);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    OMG_RD(0, smem, 0);
+    int kt = 0;
+    if (nk == 1) OMG_STAGE(false, false, false);
+    else if (nk == 2) OMG_STAGE(true, false, false);
+    else OMG_STAGE(true, true, false);
+    kt = 1;
+    for (; kt < nk - 2; ++kt) OMG_STAGE(true, true, true);
+    if (kt < nk - 1) { OMG_STAGE(true, false, true); ++kt; }
+    if (kt < nk) OMG_STAGE(false, false, true);
+    const int e_m0 = m0, e_n0 = n0, e_mend = m_end;
+    OMG_TILE(tile + (int)gridDim.x);
+    if (more) OMG_PROLOGUE();
+    epilogue_direct<T, MT, NT>(p, acc, lane, e_m0 + wm * 128, e_n0 + wn * 128, e_mend, gb_epi);
+    if (!more) break;
+  }
+#undef OMG_TILE
+#undef OMG_PREP
+#undef OMG_DMA
+#undef OMG_DMA16
+#undef OMG_PROLOGUE
+#undef OMG_RD
+#undef OMG_RD1
+#undef OMG_MM1
+#undef OMG_KSTEP
+#undef OMG_STAGE
+}
+
 constexpr int lds_bytes_v3(int bm, int bn, int nw, int nst) {
   const int ring = nst * (bm + bn) * BK3 * 2;
   const int epi = nw * 32 * STAGE_LD * 4;
@@ -1723,6 +1942,34 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v7");
 }
 
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename T, bool CONV>
+int launch_v8(GemmP p, hipStream_t s, int mrows) {
+  constexpr int lds = 2 * (256 + 256) * 64 * 2;
+  static bool attr = false;
+  if (!attr) {
+    attr = true;
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  p.tiles_m = (mrows + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  p.dbg = g_dbg;
+  const int total = p.tile_groups * p.tiles_m * p.tiles_n;
+  if (total <= 0) return OMG_OK;
+  const int grid = total < num_cus() ? total : num_cus();
+  OMG_LAUNCH((gemm_kernel_v8<T, CONV>), dim3(grid), dim3(256), lds, s, p);
+  return omg_check_launch("gemm_v8");
+}
+
 // Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered BK=64 256x256 kernel (v5) wins whenever it can put
 // >= ~120 tiles on the 256 CUs; below that the staggered 256x128 kernel if IT reaches ~120 tiles, else the 128x128
 // kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
@@ -1752,6 +1999,7 @@ int launch(const GemmP& p, hipStream_t s) {
     const long c_sz = (long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) * 2;
     const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim && c_sz < lim &&
                       (p.group_bias == nullptr || (long)(p.M / (p.rows_per_group > 0 ? p.rows_per_group : 1) + 1) * p.ldgb * 2 < lim);
+    if (v == 16) { if (v6ok) return launch_v8<T, CONV>(p, s, mrows); v = 11; }
     if (v == 15) { if (v6ok) return launch_v7<T, CONV>(p, s, mrows); v = 11; }
     if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
       if (v >= 17 && v <= 23 && v6ok) {
