@@ -1396,9 +1396,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
 //     barrier the wave starts reading the next stage's first fragments AND refilling the current buffer with stage kt+2
 //     while the last k-step's MFMAs run.
 // ABL (tools only, results are wrong): 1 = no LDS-DMA in the K loop, 2 = no fragment reads in the K loop, 4 = no wait / barrier
-template <typename T, bool CONV, int ABL = 0>
+// (MT, NT) = (4, 4): 256x256 tile.  (2, 5): 128x320 tile, wave tile 64x160 — for the layers whose width is 320 * k and
+// pads badly to 256 (N = 320: 512, N = 640: 768) or leaves a ragged last round (N = 1280 at M = 32768).
+template <typename T, bool CONV, int ABL = 0, int MT = 4, int NT = 4>
 __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
-  constexpr int BM_ = 256, BN_ = 256, BKc = 64, MT = 4, NT = 4;
+  constexpr int BM_ = MT * 64, BN_ = NT * 64, BKc = 64;
+  constexpr int AB = MT * 2, WB = NT * 2;          // A / W row blocks (8 rows each) per wave per stage
+  constexpr int NMM = MT * NT;                     // MFMAs per k-step
+  constexpr int SLOTS = NMM / 2;                   // pairs of MFMAs per k-step
+  constexpr int NRD = MT + NT;                     // fragment reads per k-step
+  static_assert(NMM % 2 == 0, "even number of MFMAs per k-step");
   constexpr int A_BYTES = BM_ * BKc * 2;
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
 
@@ -1452,11 +1459,11 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 
   // DMA: one instruction moves 8 rows x 128 B; wave w owns row blocks w, w+4, ..., w+28 of A and of W
   const int prow = lane >> 3, ppos = lane & 7;
-  int voffA[8], voffW[8];
-  int cb[8], cy[8], cx[8];
+  int voffA[AB], voffW[WB];
+  int cb[AB], cy[AB], cx[AB];
   const int dchunk = (ppos ^ ((w & 1) * 4 + (prow >> 1))) * 16;   // ((row >> 1) & 7) with row = (w + 4i) * 8 + prow
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < AB; ++i) {
     const int r = (w + i * 4) * 8 + prow;
     int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
     if constexpr (CONV) {
@@ -1468,6 +1475,10 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
       cb[i] = cy[i] = cx[i] = 0;
       voffA[i] = (int)((long)gm * p.lda * 2) + dchunk;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < WB; ++i) {
+    const int r = (w + i * 4) * 8 + prow;
     int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
     voffW[i] = (int)((long)gn * p.ldw * 2) + dchunk;
   }
@@ -1475,15 +1486,15 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 
   const int wm = w >> 1, wn = w & 1;
   f32x16 acc[MT][NT];
-  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * 128);
+  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * (NT * 32));
   using V8 = typename Vec<T>::v8;
   // fragment i of k-step ks sits at aoff[ks] + i * 4096 (32 rows further: same swizzle term)
   int aoff[4], boff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int sw = ((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    aoff[ks] = (wm * 128 + l31) * 128 + sw;
-    boff[ks] = A_BYTES + (wn * 128 + l31) * 128 + sw;
+    aoff[ks] = (wm * (MT * 32) + l31) * 128 + sw;               // (MT*32) >> 1 and (NT*32) >> 1 are multiples of 8: same swizzle term
+    boff[ks] = A_BYTES + (wn * (NT * 32) + l31) * 128 + sw;
   }
 
   int koff = 0;
@@ -1505,22 +1516,21 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
       c0b = c0 * 2; xCb = (x2 ? p.C2 : p.C1) * 2;                                                          \
     }                                                                                                      \
   } while (0)
-  // DMA instruction d of the prepared stage: d < 8 -> A row block w + 4d, else W row block w + 4(d-8)
+  // DMA instruction d of the prepared stage: d < AB -> A row block w + 4d, else W row block w + 4(d-AB); d < AB + WB
 #define OMG_DMA(d_, nb_)                                                                                   \
   do {                                                                                                     \
-    if ((d_) < 8) {                                                                                        \
-      const int i_ = (d_) & 7;                                                                             \
+    if ((d_) < AB) {                                                                                       \
+      const int i_ = (d_) < AB ? (d_) : 0;                                                                 \
       if (CONV) dma16(x2 ? rsA2 : rsA, (nb_) + ldo + i_ * 4096,                                            \
                       conv_voff(cb[i_], cy[i_], cx[i_], dchunk, p.stride, tap_dy, tap_dx, Hl, Wl, p.upsample, p.Hin, p.Win, xCb, c0b), 0); \
       else dma16(rsA, (nb_) + ldo + i_ * 4096, voffA[i_], koff);                                           \
     } else {                                                                                               \
-      const int i_ = (d_) & 7;                                                                             \
+      const int i_ = (d_) - AB < WB ? (d_) - AB : 0;                                                       \
       dma16(rsW, (nb_) + A_BYTES + ldo + i_ * 4096, voffW[i_], koff);                                      \
     }                                                                                                      \
   } while (0)
-#define OMG_DMA8(first_, nb_)                                                                              \
-  do { OMG_DMA((first_) + 0, nb_); OMG_DMA((first_) + 1, nb_); OMG_DMA((first_) + 2, nb_); OMG_DMA((first_) + 3, nb_); \
-       OMG_DMA((first_) + 4, nb_); OMG_DMA((first_) + 5, nb_); OMG_DMA((first_) + 6, nb_); OMG_DMA((first_) + 7, nb_); } while (0)
+#define OMG_DMAN(first_, n_, nb_)                                                                          \
+  do { _Pragma("unroll") for (int d_ = 0; d_ < (n_); ++d_) OMG_DMA((first_) + d_, nb_); } while (0)
 #define OMG_RD(f_, sb_, ks_)                                                                               \
   do {                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) bf[f_][j] = *(const V8*)((sb_) + boff[ks_] + j * 4096); \
@@ -1536,27 +1546,36 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   // the issue order wanted: MFMA, read, MFMA, DMA, ... — the compiler keeps LDS-DMA instructions where the source has them
 #define OMG_RD1(f_, sb_, ks_, r_)                                                                          \
   do {                                                                                                     \
-    /* read order = order of first use by the MFMAs (n = 4 i + j): W0, A0, W1, W2, W3, A1, A2, A3 */       \
-    const bool isA_ = (r_) == 1 || (r_) >= 5;                                                              \
-    const int idx_ = (r_) == 0 ? 0 : (r_) == 1 ? 0 : (r_) <= 4 ? (r_) - 1 : (r_) - 4;                      \
+    /* read order = order of first use by the MFMAs (n = NT i + j): W0, A0, W1 .. W(NT-1), A1 .. A(MT-1) */ \
+    const bool isA_ = (r_) == 1 || (r_) > NT;                                                              \
+    const int idx_ = (r_) <= 1 ? 0 : (r_) <= NT ? (r_) - 1 : (r_) - NT;                                    \
     if (!isA_) bf[f_][idx_] = *(const V8*)((sb_) + boff[ks_] + idx_ * 4096);                               \
     else af[f_][idx_] = *(const V8*)((sb_) + aoff[ks_] + idx_ * 4096);                                     \
   } while (0)
-#define OMG_MM1(f_, n_) acc[(n_) >> 2][(n_) & 3] = Vec<T>::mfma32(bf[f_][(n_) & 3], af[f_][(n_) >> 2], acc[(n_) >> 2][(n_) & 3])
+#define OMG_MM1(f_, n_) acc[(n_) / NT][(n_) % NT] = Vec<T>::mfma32(bf[f_][(n_) % NT], af[f_][(n_) / NT], acc[(n_) / NT][(n_) % NT])
   // k-step computing with fragment set f_ while set 1-f_ is refilled from (rb_, rks_) (RD_ = 1: one read per slot,
   // 2: two per slot in the first four slots, so that they are back before the loop's first MFMA needs them), and 8 DMAs
   // (instructions d0_..d0_+7 of the prepared stage into db_) are issued when DMA_
-#define OMG_KSTEP(f_, RD_, rb_, rks_, DMA_, d0_, db_)                                                      \
+  // slot s_ of a k-step: MFMA 2s, reads, MFMA 2s+1, DMAs.  RD_ = 1: reads spread over the slots (ceil(NRD / SLOTS) per
+  // slot), 2: two per slot from the first slot on.  DMA_: instructions d0_ .. d0_ + dn_ - 1, ceil(dn_ / SLOTS) per slot.
+#define OMG_KSTEP(f_, RD_, rb_, rks_, DMA_, d0_, dn_, db_)                                                 \
   do {                                                                                                     \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                     \
+    constexpr int RPS_ = (RD_) == 2 ? 2 : (NRD + SLOTS - 1) / SLOTS;                                       \
+    constexpr int DPS_ = ((dn_) + SLOTS - 1) / SLOTS;                                                      \
+    _Pragma("unroll") for (int s_ = 0; s_ < SLOTS; ++s_) {                                                 \
       OMG_MM1(f_, 2 * s_);                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if ((RD_) == 1 && !(ABL & 2)) OMG_RD1(1 - (f_), rb_, rks_, s_);                                                    \
-      if ((RD_) == 2 && s_ < 4 && !(ABL & 2)) { OMG_RD1(1 - (f_), rb_, rks_, 2 * s_); OMG_RD1(1 - (f_), rb_, rks_, 2 * s_ + 1); } \
+      if ((RD_) != 0 && !(ABL & 2)) {                                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < RPS_; ++q_)                                                \
+          if (s_ * RPS_ + q_ < NRD) OMG_RD1(1 - (f_), rb_, rks_, s_ * RPS_ + q_);                          \
+      }                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       OMG_MM1(f_, 2 * s_ + 1);                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if ((DMA_) && !(ABL & 1)) OMG_DMA((d0_) + s_, db_);                                                                  \
+      if ((DMA_) && !(ABL & 1)) {                                                                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < DPS_; ++q_)                                                \
+          if (s_ * DPS_ + q_ < (dn_)) OMG_DMA((d0_) + s_ * DPS_ + q_, db_);                                \
+      }                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
     }                                                                                                      \
   } while (0)
@@ -1564,12 +1583,12 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   V8 af[2][MT], bf[2][NT];
   // prologue: stage 0 completely, the A half of stage 1, the first fragments
   OMG_PREP(0);
-  OMG_DMA8(0, smem); OMG_DMA8(8, smem);
+  OMG_DMAN(0, AB + WB, smem);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (p.dbg & 16) ts1 = __builtin_amdgcn_s_memrealtime();
   OMG_PREP(1);
-  if (nk > 1) OMG_DMA8(0, smem + STAGE_BYTES);
+  if (nk > 1) OMG_DMAN(0, AB, smem + STAGE_BYTES);
   OMG_RD(0, smem, 0);
 
   // One stage.  HAS1_/HAS2_ (stage kt+1 / kt+2 exist) are literal so that the steady-state body is one basic block —
@@ -1579,15 +1598,15 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
     const char* cur = smem + (kt & 1) * STAGE_BYTES;                                                       \
     char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                                       \
     /* k-step 0 (+ the W half of stage kt+1), k-steps 1, 2 */                                              \
-    OMG_KSTEP(0, 1, cur, 1, HAS1_, 8, nxt);                                                                \
-    OMG_KSTEP(1, 1, cur, 2, false, 0, nxt);                                                                \
-    OMG_KSTEP(0, 1, cur, 3, false, 0, nxt);                                                                \
+    OMG_KSTEP(0, 1, cur, 1, HAS1_, AB, WB, nxt);                                                            \
+    OMG_KSTEP(1, 1, cur, 2, false, 0, 0, nxt);                                                             \
+    OMG_KSTEP(0, 1, cur, 3, false, 0, 0, nxt);                                                             \
     /* stage kt+1 has landed (this wave's part), this wave's reads of `cur` are complete: join the block */ \
     if (!(ABL & 4)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } \
     /* */                                                                                                  \
     /* k-step 3 (+ first fragments of stage kt+1, + the A half of stage kt+2 into the buffer just released) */ \
     if (HAS2_) OMG_PREP(kt + 2);                                                                           \
-    OMG_KSTEP(1, (HAS1_) ? 2 : 0, nxt, 0, HAS2_, 0, (char*)cur);                                                     \
+    OMG_KSTEP(1, (HAS1_) ? 2 : 0, nxt, 0, HAS2_, 0, AB, (char*)cur);                                                     \
   } while (0)
   int kt = 0;
   for (; kt < nk - 2; ++kt) OMG_STAGE(true, true);
@@ -1596,7 +1615,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 #undef OMG_STAGE
 #undef OMG_PREP
 #undef OMG_DMA
-#undef OMG_DMA8
+#undef OMG_DMAN
 #undef OMG_RD
 #undef OMG_MM
 #undef OMG_RD1
@@ -1614,7 +1633,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
     return;
   }
   if (p.dbg & 16) ts2 = __builtin_amdgcn_s_memrealtime();
-  epilogue_direct<T, MT, NT>(p, acc, lane, m0 + wm * 128, n0 + wn * 128, m_end, gb_epi);
+  epilogue_direct<T, MT, NT>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * (NT * 32), m_end, gb_epi);
   if (ts_on) {
     long long* t = omg_dbg_ts[blockIdx.x];
     t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memrealtime();
@@ -1922,23 +1941,22 @@ int launch_v6(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v6");
 }
 
-template <typename T, bool CONV, int ABL = 0>
+template <typename T, bool CONV, int ABL = 0, int MT = 4, int NT = 4>
 int launch_v7(GemmP p, hipStream_t s, int mrows) {
-  constexpr int ring = 2 * (256 + 256) * 64 * 2;
-  constexpr int epi = 4 * 32 * (4 * 32 + 4) * 4;
-  constexpr int lds = ring > epi ? ring : epi;
+  constexpr int BM_ = MT * 64, BN_ = NT * 64;
+  constexpr int lds = 2 * (BM_ + BN_) * 64 * 2;
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<T, CONV, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<T, CONV, ABL, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  p.tiles_m = (mrows + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
+  p.tiles_m = (mrows + BM_ - 1) / BM_;
+  p.tiles_n = (p.N + BN_ - 1) / BN_;
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
   set_stagger(p, grid, 1.7);
-  OMG_LAUNCH((gemm_kernel_v7<T, CONV, ABL>), dim3(grid), dim3(256), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v7<T, CONV, ABL, MT, NT>), dim3(grid), dim3(256), lds, s, p);
   return omg_check_launch("gemm_v7");
 }
 
@@ -1973,24 +1991,28 @@ int launch_v8(GemmP p, hipStream_t s, int mrows) {
 // Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered BK=64 256x256 kernel (v5) wins whenever it can put
 // >= ~120 tiles on the 256 CUs; below that the staggered 256x128 kernel if IT reaches ~120 tiles, else the 128x128
 // kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
-int choose_variant(int mrows, int groups, int N) {
+int choose_variant(int mrows, int groups, int N, bool conv) {
   if (g_variant != 0) return g_variant;
   const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
   const long t256x128 = (long)groups * ((mrows + 255) / 256) * ((N + 127) / 128);
-  // rounds of 256 one-block CUs x time per tile (a 256x128 tile costs ~0.58 of a 256x256 one: tools/shape_sweep.py);
-  // the narrow tile wins when N pads badly to 256 (320 -> 512) or its tile count fills the last round better
-  const double c256 = (double)((t256 + 255) / 256);
-  const double c128 = (double)((t256x128 + 255) / 256) * 0.58;
-  if (N > 128 && t256 >= 120 && c256 <= c128 * 1.06) return 15;   // 256x256 on four waves (v7); 13 = the eight-wave v6 of the same tile
-  if (t256x128 >= 120) return 14;                                  // 256x128, same structure
-  return 1;
+  const long t128x320 = (long)groups * ((mrows + 127) / 128) * ((N + 319) / 320);
+  // rounds of 256 one-block CUs x time per tile relative to a 256x256 tile of v7 (tools/shape_sweep.py,
+  // profiles/r01_shape_sweep_*.log): 256x128 on eight waves 0.58; 128x320 on four waves 0.70 (its area is 0.625).
+  // The narrow tiles win when N pads badly to 256 (320 -> 512, 640 -> 768) or they fill the last round better.
+  const double c256 = (N > 128 && t256 >= 120) ? (double)((t256 + 255) / 256) : 1e30;
+  const double c128 = t256x128 >= 120 ? (double)((t256x128 + 255) / 256) * 0.58 * 1.06 : 1e30;
+  // 128x320 only for the implicit-GEMM conv (long K): on the Linear layers' K = 640..5120 its per-tile overhead loses
+  const double c320 = (conv && N % 320 == 0 && t128x320 >= 120) ? (double)((t128x320 + 255) / 256) * 0.70 : 1e30;
+  if (c320 < c256 && c320 < c128) return 24;
+  if (c256 <= c128) return c256 < 1e30 ? 15 : 1;   // 256x256 on four waves (v7); 13 = the eight-wave v6 of the same tile
+  return 14;                                       // 256x128 on eight waves (v6)
 }
 
 template <typename T, bool CONV>
 int launch(const GemmP& p, hipStream_t s) {
   const int mrows = p.tile_groups > 1 ? p.rows_per_group : p.M;
   if (g_use_glds) {
-    int v = choose_variant(mrows, p.tile_groups, p.N);
+    int v = choose_variant(mrows, p.tile_groups, p.N, CONV);
     if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4, 4>(p, s, mrows);
     if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2, 4>(p, s, mrows);
     // v6 (interleaved DMA) handles everything except the LoRA second K-segment and > 2 GiB operands
@@ -1999,6 +2021,8 @@ int launch(const GemmP& p, hipStream_t s) {
     const long c_sz = (long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) * 2;
     const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim && c_sz < lim &&
                       (p.group_bias == nullptr || (long)(p.M / (p.rows_per_group > 0 ? p.rows_per_group : 1) + 1) * p.ldgb * 2 < lim);
+    if (v == 24 && p.act == OMG_ACT_GEGLU) v = 15;      // a 160-wide wave tile cannot hold whole [32 value | 32 gate] blocks
+    if (v == 24) { if (v6ok) return launch_v7<T, CONV, 0, 2, 5>(p, s, mrows); v = 12; }
     if (v == 16) { if (v6ok) return launch_v8<T, CONV>(p, s, mrows); v = 11; }
     if (v == 15) { if (v6ok) return launch_v7<T, CONV>(p, s, mrows); v = 11; }
     if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
