@@ -50,8 +50,6 @@ struct GemmP {
   int Hin, Win, C1, C2, Hout, Wout, ksize, stride, upsample;
   const char* X2;
   int tiles_m, tiles_n;              // tiles_m is per group
-  int stagger_ticks;                 // first-round start delay step in 10 ns ticks (0 = none), see stagger_start()
-  int stagger_groups;
   int dbg;                           // ablation bits (tools only): 1 = no DMA in loop, 2 = no wait/barrier, 4 = no ds_read
 };
 
@@ -412,8 +410,7 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
-          const long gms = (p.dbg & 512) ? (gm & 255) : gm;   // tools only: L2-resident destination
-          if (!(p.dbg & 256) || o[0] == 1.2345e-30f) *(u32x4*)(p.C + (gms * p.ldc + ((wn0 + blk * 64) >> 1) + c8) * 2) = pack8<T>(o);
+          *(u32x4*)(p.C + ((long)gm * p.ldc + ((wn0 + blk * 64) >> 1) + c8) * 2) = pack8<T>(o);
         }
       }
     } else {
@@ -446,8 +443,7 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
           }
-          const long gms = (p.dbg & 512) ? (gm & 255) : gm;   // tools only: L2-resident destination
-          if (!(p.dbg & 256) || v[0] == 1.2345e-30f) *(u32x4*)(p.C + (gms * p.ldc + gc) * 2) = pack8<T>(v);
+          *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
         }
       }
     }
@@ -493,14 +489,11 @@ OMG_DEV void store_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, const floa
   unsigned q[4] = {pk[0], pk[1], pk[2], pk[3]};
   swap_runs<T>(q);
   u32x4 sw = {q[0], q[1], q[2], q[3]};
-#ifndef OMG_STORE_AUX
-#define OMG_STORE_AUX 0
-#endif
   // The constant goes into the VGPR offset, never into an SGPR soffset: with `buffer_store_dwordx4 ..., s1 offen` the VALU
   // instruction right behind the store overwrote dword 2 of the store data in the last lanes of each row before the
   // store had read it (observed: the next row block's row index in the output; tools/debug_gemm_small.py).  hipcc adds
   // the wait state only when soffset is an immediate.
-  __builtin_amdgcn_raw_buffer_store_b128(sw, rs, off + soff, 0, OMG_STORE_AUX);
+  __builtin_amdgcn_raw_buffer_store_b128(sw, rs, off + soff, 0, 0);
 }
 
 // Accumulators start at the bias instead of zero (one add per output saved in the epilogue, where a wave has no
@@ -1113,20 +1106,6 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
 }
 
-// Desynchronise the CUs of a one-block-per-CU kernel.  All first-round blocks start together and every tile takes the same
-// time, so without this all 256 CUs reach their epilogue at the same moment: 32 MB of C rows hit HBM at once (measured
-// 12-19 us per round at ~2.6 TB/s with the matrix cores idle) and then HBM idles for the whole next main loop.  Delaying
-// group g of the first round by g/G of a tile time puts one group's epilogue under the other groups' main loops for the
-// rest of the launch; later rounds inherit the phase of the CU they land on.
-OMG_DEV void stagger_start(const GemmP& p) {
-  if (p.stagger_ticks <= 0 || (int)blockIdx.x >= 256) return;
-  const int g = ((int)blockIdx.x >> 3) % p.stagger_groups;
-  if (g == 0) return;
-  const unsigned long t0 = __builtin_amdgcn_s_memrealtime();
-  const unsigned long wait = (unsigned long)g * (unsigned long)p.stagger_ticks;
-  while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-}
-
 // 16 bytes per lane, global -> LDS, through a buffer descriptor.  A non-template wrapper on purpose: with value-dependent
 // arguments the builtin's checks are deferred to instantiation time, where the host pass of hipcc silently drops the kernel.
 OMG_DEV void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
@@ -1164,7 +1143,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
   constexpr int A_BYTES = BM_ * BKc * 2;
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
 
-  stagger_start(p);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1379,7 +1357,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
     if (sacc == 1.2345e-30f) p.C[0] = 1;
     return;
   }
-  if (p.dbg & 2048) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
   epilogue_direct<T, MT, NT>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * 64, m_end, gb_epi);
 }
 
@@ -1412,7 +1389,6 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   const bool ts_on = (p.dbg & 16) && blockIdx.x < 8192 && threadIdx.x == 0;
   long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (p.dbg & 16) ts0 = __builtin_amdgcn_s_memrealtime();
-  stagger_start(p);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1909,17 +1885,6 @@ int launch_v5(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v5");
 }
 
-// first-round start delays (stagger_start): G groups, step = tile time / G; us_per_stage is the measured main-loop time
-// of one BK=64 stage of the kernel
-void set_stagger(GemmP& p, int grid, double us_per_stage) {
-  p.stagger_ticks = 0; p.stagger_groups = 1;
-  const int G = (g_dbg & 64) ? 2 : (g_dbg & 128) ? 4 : 0;
-  if (G == 0 || grid <= 256) return;
-  const double tile_us = ((p.K + 63) / 64) * us_per_stage + 3.0;
-  p.stagger_groups = G;
-  p.stagger_ticks = (int)(tile_us * 100.0 / G);
-}
-
 template <typename T, bool CONV, int MT>
 int launch_v6(GemmP p, hipStream_t s, int mrows) {
   constexpr int BN_ = MT == 4 ? 256 : 128;
@@ -1936,7 +1901,6 @@ int launch_v6(GemmP p, hipStream_t s, int mrows) {
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  set_stagger(p, grid, MT == 4 ? 1.8 : 1.0);
   OMG_LAUNCH((gemm_kernel_v6<T, CONV, MT>), dim3(grid), dim3(512), lds, s, p);
   return omg_check_launch("gemm_v6");
 }
@@ -1955,7 +1919,6 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  set_stagger(p, grid, 1.7);
   OMG_LAUNCH((gemm_kernel_v7<T, CONV, ABL, MT, NT>), dim3(grid), dim3(256), lds, s, p);
   return omg_check_launch("gemm_v7");
 }
