@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMG_ABI_VERSION 2
+#define OMG_ABI_VERSION 3
 
 enum { OMG_F16 = 0, OMG_BF16 = 1, OMG_F32 = 2 /* only where a signature says so */ };
 
@@ -194,6 +194,17 @@ int omg_silu(int dtype, const void* x, void* y, int64_t n, void* stream);
 /* y[i] += a[i]  (ControlNet residuals added to the UNet skip tensors: `sample += residual`,
  * diffusers unet_2d_condition.py, reached from lora_pipeline.py:546-556) */
 int omg_add_inplace(int dtype, void* y, const void* a, int64_t n, void* stream);
+/* ------------------------------------------------------------------------
+ * VAE decode (row N1): the two pieces AutoencoderKL.decode needs beyond the UNet's kernels
+ * (diffusers 0.25.0 models/autoencoder_kl.py `post_quant_conv`, models/attention_processor.py
+ * `Attention` with ONE head of dim C over all H*W tokens; reached from lora_pipeline.py:635-661).
+ *   omg_softmax_rows : X[r, 0:cols] = softmax(X[r, 0:cols] * scale) in place, fp32 math, rows of `ld` elements
+ *                      (the (HW x HW) score matrix of the mid-block attention, produced and consumed by omg_gemm).
+ *   omg_channel_mix  : NCHW fp32, Y[b, o, p] = bias[o] + sum_c Wm[o, c] * X[b, c, p]   (1x1 conv, Cin, Cout <= 8)
+ * ---------------------------------------------------------------------- */
+int omg_softmax_rows(int dtype, void* X, int64_t rows, int64_t cols, int64_t ld, float scale, void* stream);
+int omg_channel_mix(const float* X, const float* Wm, const float* bias, int B, int Cin, int Cout, int64_t HW,
+                    float* Y, void* stream);
 /* dst[r, col0 : col0+cols] = src[r, 0:cols]  (row-wise copy with strides, elements) */
 int omg_copy2d(int dtype, const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
 

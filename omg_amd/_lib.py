@@ -81,6 +81,8 @@ SYMBOLS = {
     "omg_conv_out": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "omg_timestep_embedding": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "omg_silu": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "omg_softmax_rows": (c_i32, [c_i32, c_vp, c_i64, c_i64, c_i64, C.c_float, c_vp]),
+    "omg_channel_mix": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i64, c_vp, c_vp]),
     "omg_add_inplace": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp]),
     "omg_copy2d": (c_i32, [c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "omg_fuse_cfg_step": (c_i32, [C.POINTER(StepArgs), c_vp]),
@@ -120,7 +122,7 @@ def lib() -> C.CDLL:
         fn = getattr(l, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if l.omg_abi_version() != 2:
+    if l.omg_abi_version() != 3:
         raise OmgHipError("libomg_hip.so ABI version mismatch; rebuild")
     v = os.environ.get("OMG_GEMM_VARIANT")      # debugging/benchmarking aid: force one GEMM tile configuration
     if v:

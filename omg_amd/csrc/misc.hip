@@ -255,6 +255,65 @@ extern "C" int omg_timestep_embedding(int dtype, const float* t, int n, int dim,
   return omg_check_launch("timestep_embedding");
 }
 
+// ---------------------------------------------------------------- VAE decode helpers (row N1)
+// one 256-thread block per row; the row (<= 16384 columns for a 128x128 latent) is read twice (max, then exp + sum) and
+// written once: HBM / L2 bound, 3 x cols x 2 bytes per row
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* X, long cols, long ld, float scale) {
+  __shared__ float red[8];
+  T* row = X + (long)blockIdx.x * ld;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float m = -3.0e38f;
+  for (long c = tid; c < cols; c += 256) m = fmaxf(m, (float)row[c]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[w] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+  const float sl2 = scale * 1.4426950408889634f, ml2 = m * 1.4426950408889634f;
+  float sum = 0.f;
+  for (long c = tid; c < cols; c += 256) sum += __builtin_amdgcn_exp2f((float)row[c] * sl2 - ml2);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) red[4 + w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (long c = tid; c < cols; c += 256) row[c] = (T)(__builtin_amdgcn_exp2f((float)row[c] * sl2 - ml2) * inv);
+}
+
+__global__ __launch_bounds__(256) void channel_mix_kernel(const float* X, const float* Wm, const float* bias, int Cin, int Cout,
+                                                          long HW, float* Y) {
+  const int b = blockIdx.y;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    float x[8];
+    for (int c = 0; c < Cin; ++c) x[c] = X[((long)b * Cin + c) * HW + p];
+    for (int o = 0; o < Cout; ++o) {
+      float a = bias ? bias[o] : 0.f;
+      for (int c = 0; c < Cin; ++c) a = __fmaf_rn(Wm[o * Cin + c], x[c], a);
+      Y[((long)b * Cout + o) * HW + p] = a;
+    }
+  }
+}
+
+extern "C" int omg_softmax_rows(int dtype, void* X, int64_t rows, int64_t cols, int64_t ld, float scale, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_softmax_rows: dtype");
+  OMG_REQUIRE(X && rows >= 0 && cols > 0 && ld >= cols && rows < 2147483647L, "omg_softmax_rows: args");
+  if (rows == 0) return OMG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMG_F16) OMG_LAUNCH(softmax_rows_kernel<f16>, dim3((unsigned)rows), dim3(256), 0, s, (f16*)X, (long)cols, (long)ld, scale);
+  else OMG_LAUNCH(softmax_rows_kernel<bf16>, dim3((unsigned)rows), dim3(256), 0, s, (bf16*)X, (long)cols, (long)ld, scale);
+  return omg_check_launch("softmax_rows");
+}
+
+extern "C" int omg_channel_mix(const float* X, const float* Wm, const float* bias, int B, int Cin, int Cout, int64_t HW,
+                               float* Y, void* stream) {
+  OMG_REQUIRE(X && Wm && Y && B >= 0 && HW > 0, "omg_channel_mix: args");
+  OMG_REQUIRE(Cin >= 1 && Cin <= 8 && Cout >= 1 && Cout <= 8, "omg_channel_mix: 1 <= Cin, Cout <= 8");
+  if (B == 0) return OMG_OK;
+  long blocks = (HW + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  OMG_LAUNCH(channel_mix_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, X, Wm, bias, Cin, Cout, (long)HW, Y);
+  return omg_check_launch("channel_mix");
+}
+
 extern "C" int omg_silu(int dtype, const void* x, void* y, int64_t n, void* stream) {
   OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_silu: dtype");
   OMG_REQUIRE(x && y, "omg_silu: null");

@@ -351,6 +351,28 @@ def conv_out(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
+def softmax_rows_(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """In-place ``softmax(x * scale, dim=-1)`` of a 2-D tensor with unit inner stride (VAE mid-block attention scores)."""
+    _dev(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    L.check(L.lib().omg_softmax_rows(_dt(x), x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), float(scale), _stream()),
+            "omg_softmax_rows")
+    return x
+
+
+def channel_mix(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """fp32 NCHW 1x1 convolution with at most 8 channels on either side (AutoencoderKL.post_quant_conv)."""
+    _dev(x_nchw)
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w.dtype == torch.float32 and w.is_contiguous()
+    B, Cin, H, W = x_nchw.shape
+    Cout = w.shape[0]
+    assert w.numel() == Cout * Cin and (bias is None or (bias.dtype == torch.float32 and bias.numel() == Cout))
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_nchw.device)
+    L.check(L.lib().omg_channel_mix(x_nchw.data_ptr(), w.data_ptr(), _p(bias), B, Cin, Cout, H * W, y.data_ptr(), _stream()),
+            "omg_channel_mix")
+    return y
+
+
 def timestep_embedding(t: torch.Tensor, dim: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """t: fp32 device tensor [n] -> [n, dim] (cos | sin), written into `out` (may be a column slice)."""
     _dev(t)

@@ -7,10 +7,11 @@ same keyword names and meaning for everything on the hot path (``num_inference_s
 layout: latents duplicated x2 (:409), model input ``[unc0, unc1, cond0, cond1]`` (:467-474, :491), concept
 pass on ``latent_model_input[3:4]`` duplicated (:583-585), fusion for ``i > 15 and stage == 2`` (:568).
 
-What is NOT here (rows marked "next" in SURVEY §8f): text encoders and the VAE.  The call therefore takes
-``prompt_embeds`` / pooled embeddings (the reference computes them at :315-347 and passes them on) and
-returns latents (``output_type="latent"``); ``prompt=``/``output_type="pil"`` work only if the caller
-supplies ``encode_prompt`` / ``vae_decode`` callables.
+What is NOT here (row N4 of SURVEY §8f): the text encoders.  The call therefore takes ``prompt_embeds`` / pooled
+embeddings (the reference computes them at :315-347 and passes them on) and returns latents
+(``output_type="latent"``), or decoded images in [0, 1] when the pipeline was built with
+``vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents`` (row N1; the reference's tail at :635-661);
+``prompt=`` works only if the caller supplies an ``encode_prompt`` callable.
 
 MI355X-first differences from the reference's loop, all value-preserving:
   * the K per-concept UNet passes of a step run as ONE batched forward with a per-sample LoRA slot;
@@ -209,7 +210,8 @@ class LoraMultiConceptPipeline:
             images = lat
         else:
             if self.vae_decode is None:
-                raise L.OmgHipError("VAE decode is a 'next' row (SURVEY §8f N1): use output_type='latent' or pass vae_decode=")
+                raise L.OmgHipError("no VAE attached: use output_type='latent' or construct the pipeline with "
+                                    "vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents")
             images = self.vae_decode(lat)
         if not return_dict:
             return (images,)
@@ -534,6 +536,7 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
             trajectory.extend(t[0] for t in traj_many)
         if output_type != "latent":
             if self.vae_decode is None:
-                raise L.OmgHipError("VAE decode is a 'next' row (SURVEY §8f N1): use output_type='latent' or pass vae_decode=")
+                raise L.OmgHipError("no VAE attached: use output_type='latent' or construct the pipeline with "
+                                    "vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents")
             lat = self.vae_decode(lat)
         return StableDiffusionXLPipelineOutput(images=lat) if return_dict else (lat,)

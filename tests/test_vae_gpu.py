@@ -1,0 +1,119 @@
+"""Row N1: AutoencoderKL.decode on the HIP kernels vs the fp32 oracle (oracle/vae.py).
+Tolerances: the decoder is ~30 convolution / normalisation layers deep with 16-bit storage between them; the checks are
+on the error relative to the output's rms (fp16: 1.5e-2 rms, 6e-2 max; bf16: 6e-2 rms, 2.5e-1 max)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from omg_amd import ops
+from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
+from oracle import vae as ov
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: (1.5e-2, 6e-2), torch.bfloat16: (6e-2, 2.5e-1)}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _build(cfg_o, cfg_p, dtype, dev, seed=0):
+    sd = ov.init_state_dict(cfg_o, seed=seed)
+    vae = AutoencoderKLDecoder(cfg_p, dtype=dtype, device=dev)
+    vae.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    # the oracle sees the same 16-bit rounded weights (post_quant_conv stays fp32 on both sides)
+    sd_r = {k: (v if k.startswith("post_quant_conv") else v.to(dtype).float()) for k, v in sd.items()}
+    return sd_r, vae
+
+
+def _check(out, ref, dtype):
+    rms_tol, max_tol = TOL[dtype]
+    ref = ref.float()
+    diff = out.float().cpu() - ref
+    rms = ref.pow(2).mean().sqrt()
+    assert torch.isfinite(out).all()
+    assert diff.pow(2).mean().sqrt() / rms < rms_tol, f"rms error {diff.pow(2).mean().sqrt() / rms:.3e}"
+    assert diff.abs().max() / rms < max_tol, f"max error {diff.abs().max() / rms:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_softmax_rows_and_channel_mix(dev, dtype):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(70, 1000, generator=g) * 3).to(dtype)
+    big = torch.zeros(70, 1024, dtype=dtype)
+    big[:, :1000] = x
+    xd = big.to(dev)
+    ops.softmax_rows_(xd[:, :1000], 0.37)
+    ref = torch.softmax(x.float() * 0.37, dim=-1)
+    torch.testing.assert_close(xd[:, :1000].float().cpu(), ref, rtol=2e-2 if dtype == torch.bfloat16 else 4e-3, atol=1e-5)
+    assert torch.equal(xd[:, 1000:].cpu(), torch.zeros(70, 24, dtype=dtype))           # padding columns untouched
+    z = torch.randn(3, 4, 9, 7, generator=g)
+    w, b = torch.randn(4, 4, 1, 1, generator=g), torch.randn(4, generator=g)
+    y = ops.channel_mix(z.to(dev), w.reshape(4, 4).contiguous().to(dev), b.to(dev))
+    torch.testing.assert_close(y.cpu(), F.conv2d(z, w, b), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_decode_tiny_matches_oracle(dev, dtype):
+    cfg_o = ov.VaeConfig.tiny()
+    sd, vae = _build(cfg_o, VaeConfig.tiny(), dtype, dev)
+    z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(1))
+    taps = {}
+    ref = ov.decode(sd, cfg_o, z, taps)
+    out = vae.decode(z.to(dev))
+    assert out.shape == (2, 3, 32, 32) and out.dtype == torch.float32
+    _check(out, ref, dtype)
+    # the reference's tail: divide by the scaling factor, decode, denormalise (lora_pipeline.py:650-661)
+    img = vae.decode_latents(z.to(dev) * cfg_o.scaling_factor)
+    ref_img = ov.postprocess(ref)
+    assert (img.cpu() - ref_img).abs().max() < (0.06 if dtype == torch.float16 else 0.2)
+
+
+def test_decode_sdxl_width_small_latent(dev):
+    """Full SDXL channel widths (512/512/256/128, 3 resnets per block, 512-dim single-head attention) on a 16x16 latent."""
+    dtype = torch.float16
+    cfg_o = ov.VaeConfig.sdxl()
+    sd, vae = _build(cfg_o, VaeConfig.sdxl(), dtype, dev, seed=3)
+    z = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(2))
+    ref = ov.decode(sd, cfg_o, z)
+    out = vae.decode(z.to(dev))
+    assert out.shape == (1, 3, 128, 128)
+    _check(out, ref, dtype)
+
+
+def test_decoder_refuses_cpu_tensors(dev):
+    vae = AutoencoderKLDecoder(VaeConfig.tiny(), dtype=torch.float16, device=dev).init_synthetic_(0)
+    with pytest.raises(Exception):
+        vae.decode(torch.zeros(1, 4, 8, 8))
+
+
+def test_pipeline_decodes_through_the_vae(dev):
+    """output_type != 'latent' runs the reference's tail (lora_pipeline.py:635-661) on the decoder attached as vae_decode."""
+    import contextlib, io
+    from omg_amd import controller as pc
+    from omg_amd.pipeline import LoraMultiConceptPipeline, revise_regionally_controlnet_forward
+    from omg_amd.schedulers import make_scheduler
+    from omg_amd.synthetic import c2_inputs, c2_masks, make_concept_models
+    from omg_amd.unet import UNet2DConditionModel, UNetConfig
+    dtype = torch.float16
+    cfg = UNetConfig.tiny()
+    unet = UNet2DConditionModel(cfg, dtype=dtype, device=dev).init_synthetic_(0)
+    HW = cfg.sample_size * 8
+    P = "a man and a woman"
+    ctl = pc.AttentionReplace([P, P], 4, {"default_": 1.0}, 0.4, HW // 32, HW // 32, device=dev, dtype=dtype)
+    with contextlib.redirect_stdout(io.StringIO()):
+        revise_regionally_controlnet_forward(unet, ctl)
+    concept = make_concept_models(unet, n_concepts=2, rank=8)
+    vae = AutoencoderKLDecoder(VaeConfig.tiny(), dtype=dtype, device=dev).init_synthetic_(0)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"), vae_decode=vae.decode_latents)
+    kw = dict(num_inference_steps=4, height=HW, width=HW, guidance_scale=7.5, cross_attention_kwargs={"scale": 0.8}, controller=ctl,
+              concept_models=concept, stage=2, region_masks=c2_masks(HW, HW, device=dev), lora_list=["concept0", "concept1"],
+              styleL=False, **c2_inputs(unet, 0, height=HW, width=HW))
+    lat = pipe(output_type="latent", **kw).images
+    ctl.reset()
+    img = pipe(output_type="pt", **kw).images
+    up = 2 ** (len(vae.config.block_out_channels) - 1)          # 2 for the tiny decoder, 8 for SDXL's
+    assert img.shape == (lat.shape[0], 3, lat.shape[2] * up, lat.shape[3] * up) and img.dtype == torch.float32
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    assert torch.equal(img, vae.decode_latents(lat))
