@@ -48,17 +48,20 @@ def _read_tensors(path_or_dict) -> Dict[str, torch.Tensor]:
 
 
 # ---------------------------------------------------------------------------------------------- model checkpoints
-def load_model_weights(model: torch.nn.Module, path_or_dict, *, strict: bool = True, prefix: str = "") -> List[str]:
+def load_model_weights(model: torch.nn.Module, path_or_dict, *, strict: bool = True, prefix: str = "",
+                       allow_extra: bool = False) -> List[str]:
     """Load a diffusers-layout checkpoint (``diffusion_pytorch_model[.fp16].safetensors`` of a UNet / ControlNet) into
-    ``model``.  ``prefix`` strips a leading namespace (``"unet."`` for a whole-pipeline single file).  Shapes are checked
-    before anything is copied; dtype follows the model (fp32 files are rounded once).  Returns the ignored keys."""
+    ``model``.  ``prefix`` strips a leading namespace (``"unet."`` for a whole-pipeline single file).  ``allow_extra``
+    accepts a file that holds more than the model (a full VAE file for the decoder-only module) while still requiring every
+    tensor of the model.  Shapes are checked before anything is copied; dtype follows the model (fp32 files are rounded
+    once).  Returns the ignored keys."""
     sd = _read_tensors(path_or_dict)
     if prefix:
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     own = model.state_dict()
     missing = [k for k in own if k not in sd]
     extra = [k for k in sd if k not in own]
-    if strict and (missing or extra):
+    if strict and (missing or (extra and not allow_extra)):
         raise LoaderError(f"checkpoint does not match {type(model).__name__}: {len(missing)} missing (e.g. {missing[:3]}), "
                           f"{len(extra)} unexpected (e.g. {extra[:3]})")
     bad = [(k, tuple(sd[k].shape), tuple(own[k].shape)) for k in own if k in sd and sd[k].shape != own[k].shape]

@@ -4,7 +4,7 @@ then ``image_processor.postprocess``).
 
 State-dict keys equal diffusers' (``post_quant_conv.*``, ``decoder.conv_in``, ``decoder.mid_block.{resnets,attentions}``,
 ``decoder.up_blocks.i.{resnets.j,upsamplers.0.conv}``, ``decoder.conv_norm_out``, ``decoder.conv_out``) so that
-``omg_amd.loaders.load_model_weights(vae, "vae/diffusion_pytorch_model.safetensors", strict=False)`` fills the decoder from
+``omg_amd.loaders.load_model_weights(vae, "vae/diffusion_pytorch_model.safetensors", allow_extra=True)`` fills the decoder from
 a full VAE file (the encoder / quant_conv entries are returned as ignored).
 
 Every convolution is the implicit-GEMM MFMA kernel on NHWC activations (nearest-2x upsample folded into the consumer's

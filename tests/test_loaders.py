@@ -101,3 +101,20 @@ def test_model_checkpoint_round_trip(unet, tmp_path):
     bad["conv_in.bias"] = torch.zeros(3)
     with pytest.raises(loaders.LoaderError, match="shape mismatch"):
         loaders.load_model_weights(other, bad)
+
+
+def test_decoder_only_vae_loads_from_a_full_vae_file():
+    from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
+    vae = AutoencoderKLDecoder(VaeConfig.tiny(), dtype=torch.float16, device="cpu")
+    g = torch.Generator().manual_seed(2)
+    sd = {k: torch.randn(v.shape, generator=g).to(v.dtype) for k, v in vae.state_dict().items()}
+    full = dict(sd)
+    full["encoder.conv_in.weight"] = torch.zeros(8, 3, 3, 3)
+    full["quant_conv.weight"] = torch.zeros(8, 8, 1, 1)
+    with pytest.raises(loaders.LoaderError, match="unexpected"):
+        loaders.load_model_weights(vae, full)
+    assert sorted(loaders.load_model_weights(vae, full, allow_extra=True)) == ["encoder.conv_in.weight", "quant_conv.weight"]
+    assert all(torch.equal(v, sd[k]) for k, v in vae.state_dict().items())
+    full.pop("decoder.conv_out.bias")
+    with pytest.raises(loaders.LoaderError, match="1 missing"):
+        loaders.load_model_weights(vae, full, allow_extra=True)
