@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (NOT a valid benchmark)")
     ap.add_argument("--images-per-step", type=int, default=8, help="independent requests run in lock-step per step (one batched UNet forward)")
     ap.add_argument("--by-shape", default="", help="also write the roofline leg's per-shape table (ms per bench step, TF/s) to this file")
+    ap.add_argument("--no-vae", action="store_true", help="stop at the latents (skip the VAE decode that ends the reference's stage-2 call)")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
 
@@ -105,6 +106,10 @@ def main():
     _quiet(revise_regionally_controlnet_forward, unet, ctl)       # the installer prints like the reference's; stdout must stay ONE JSON line
     concept = make_concept_models(unet, n_concepts=2, rank=64 if not args.tiny else 8)
     pipe = LoraMultiConceptPipeline(unet, make_scheduler(args.scheduler))
+    vae = None
+    if not args.no_vae:           # the tail of the reference's call: vae.decode(latents / scaling_factor) + postprocess (lora_pipeline.py:635-661)
+        from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
+        vae = AutoencoderKLDecoder(VaeConfig.tiny() if args.tiny else VaeConfig.sdxl(), dtype=torch.bfloat16, device=dev).init_synthetic_(seed=1)
     masks = c2_masks(HW, HW, device=dev)
     n_steps = args.warmup + args.steps
     ips = args.images_per_step
@@ -120,9 +125,14 @@ def main():
     def run_step(reqs):
         """One bench step = `ips` complete stage-2 calls (independent requests batched through the UNet in lock-step)."""
         ctl.reset()                                                                   # inference_lora.py:274
-        return pipe.generate_many(reqs, height=HW, width=HW, num_inference_steps=args.denoise_steps, guidance_scale=7.5,
-                                  cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
-                                  lora_list=["concept0", "concept1"], styleL=False, use_graph=not args.no_graph)
+        lat = pipe.generate_many(reqs, height=HW, width=HW, num_inference_steps=args.denoise_steps, guidance_scale=7.5,
+                                 cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
+                                 lora_list=["concept0", "concept1"], styleL=False, use_graph=not args.no_graph)
+        if vae is not None:                                                           # both images of every request, two at a time
+            for j in range(lat.shape[0]):
+                img = vae.decode_latents(lat[j])
+            assert img.shape[-1] == lat.shape[-1] * 2 ** (len(vae.config.block_out_channels) - 1)
+        return lat
 
     for i in range(args.warmup):
         lat = run_step(inputs[i])
@@ -147,6 +157,7 @@ def main():
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),
                       "global_batch": world * ips, "images_per_step_per_gpu": ips, "main_batch": 4 * ips, "concept_batch": 4 * ips, "accounting": "stage-2 only, as executed by the reference "
                       "(200 main + 136 concept sample-forwards = 2.273 PFLOP/image); no redundancy shortcuts",
+                      "vae_decode": "skipped (--no-vae)" if args.no_vae else "both 1024^2 images of every request decoded inside the timed region (bf16 storage, fp32 accumulate; +10.5 TFLOP per request, not counted in the FLOP accounting)",
                       "parallelism": f"dp{world}", "tiny_debug": bool(args.tiny),
                       "step_loop": "eager" if args.no_graph else "hipGraph replay (3 captured step regimes)", "lora": "merged weight slots, "
                       "main + concept samples of all requests batched per fused step (8 samples per request)"},
