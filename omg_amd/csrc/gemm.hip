@@ -19,7 +19,7 @@
 #include "common.h"
 
 __device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
-__device__ long long omg_dbg_cycles[8][8];
+
 __device__ long long omg_dbg_ts[8192][6];   // tools only: per-block timestamps (dbg bit 16): start, stage 0 landed, loop end, epilogue issued, HW_ID, XCC_ID   // tools only: per-wave phase cycle totals of block 0 (dbg bit 16)
 
 namespace {
@@ -340,19 +340,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// v3: large-tile, deep-ring variant.  L2 -> LDS traffic is what bounds the 128x128 tile on MI355X
-// (64 FLOP per staged byte: ~12 TB/s of LDS-DMA at 770 TF/s), so v3 raises the block tile to 256x256
-// (128 FLOP/B) or 256x128 and keeps the wave tile N at 64 (so the GEGLU value|gate pairing and the
-// row-coalesced epilogue are unchanged).  BK = 32 stages in a 4-deep LDS ring filled by LDS-DMA three
-// stages ahead; ONE raw s_barrier per stage; COUNTED vmcnt (never 0 in steady state) so two stages stay
-// in flight across the barrier (cdna guide §5 "Pipelining across barriers").
-//   BM x BN   waves (M x N)  wave tile   threads  LDS ring      blocks/CU
-//   256x256   2 x 4          128 x 64    512      4 x 32 KiB    1
-//   256x128   4 x 2           64 x 64    512      4 x 24 KiB    1
-// LDS image per stage: rows of 64 B (4 chunks of 16 B), chunk ^= (row >> 2) & 3 (16 lanes of a
-// ds_read_b128 group -> 16 distinct slots); applied on the DMA source side and on the read (rule 21).
-constexpr int BK3 = 32;
-
+// Large-tile kernels (v5 .. v8): 256-row block tiles, LDS stages of BK = 64 filled by LDS-DMA, raw s_barrier + explicit
+// s_waitcnt instead of __syncthreads.  LDS image per stage: rows of 128 B (8 chunks of 16 B), chunk ^= (row >> 1) & 7,
+// applied on the DMA source side and on the fragment read.
 template <int N> OMG_DEV void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt range");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -638,270 +628,14 @@ OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, in
   }
 }
 
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST3, bool STAG>
-__global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v3(GemmP p) {
-  constexpr int NW = WM_ * WN_;
-  constexpr int MT = BM_ / WM_ / 32;             // 32-row MFMA tiles per wave (2 or 4)
-  constexpr int NT = BN_ / WN_ / 32;             // must be 2
-  static_assert(NT == 2, "wave tile N must be 64");
-  constexpr int A_BYTES = BM_ * BK3 * 2;
-  constexpr int STAGE_BYTES = (BM_ + BN_) * BK3 * 2;
-  constexpr int A_INSTR = BM_ / 16 / NW;         // DMA instructions per wave per stage for A
-  constexpr int B_INSTR = BN_ / 16 / NW;
-  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
-  constexpr int NDMA = A_INSTR + B_INSTR;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tiles_per_group = p.tiles_m * p.tiles_n;
-  const int grp = bid / tiles_per_group;
-  const int t_in = bid - grp * tiles_per_group;
-  // grouped ordering: 8 M-tiles x all N-tiles per group, M fastest inside the group, so that the ~32 consecutive
-  // tiles an XCD receives touch ~8 A panels + <= 4..5 W panels instead of 32 + 1 (tall-skinny GEMMs re-read A per N tile)
-  int tm, tn;
-  {
-    const int per_group = 8 * p.tiles_n;
-    const int gid = t_in / per_group;
-    const int first_m = gid * 8;
-    const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
-    const int r = t_in - gid * per_group;
-    tm = first_m + (r % gsz);
-    tn = r / gsz;
-  }
-  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
-  const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
-  const int m0 = m_base + tm * BM_;
-  const int n0 = tn * BN_;
-
-  int adapter = 0;
-  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
-  const bool seg2 = (p.K2 > 0) && (adapter >= 0);
-  if (p.w_adapter_stride != 0 && adapter < 0) return;
-  const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
-  const char* W2p = p.W2 + (seg2 ? (long)adapter * p.w2_adapter_stride * 2 : 0);
-  const int a2off = (p.a2_col_block > 0) ? (n0 / p.a2_col_block) * p.K2 : 0;
-
-  const int nk1 = (p.K + BK3 - 1) / BK3;
-  const int nk2 = seg2 ? (p.K2 + BK3 - 1) / BK3 : 0;
-  const int nk = nk1 + nk2;
-
-  // ---- staging coordinates.  DMA instruction j of an operand covers rows [j*16, j*16+16); wave w issues
-  // instructions j = w + i*NW.  lane -> (row = lane>>2, 16-B position = lane&3).
-  const int prow = lane >> 2;
-  const int ppos = lane & 3;
-  const char* zero = (const char*)omg_zero_page;
-  const char* a_ptr[A_INSTR];      // plain GEMM: row base of A (segment 1) incl. source chunk
-  const char* a2_ptr[A_INSTR];
-  const char* w_ptr[B_INSTR];
-  const char* w2_ptr[B_INSTR];
-  int a_chunk[A_INSTR], w_chunk[B_INSTR];
-  int cb[A_INSTR], cy[A_INSTR], cx[A_INSTR];
-#pragma unroll
-  for (int i = 0; i < A_INSTR; ++i) {
-    const int r = (w + i * NW) * 16 + prow;
-    int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
-    const int c = ppos ^ ((r >> 2) & 3);
-    a_chunk[i] = c;
-    if constexpr (CONV) {
-      const int hw = p.Hout * p.Wout;
-      const int b = gm / hw; const int rem = gm - b * hw;
-      cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;
-      a_ptr[i] = nullptr; a2_ptr[i] = nullptr;
-    } else {
-      a_ptr[i] = p.A + ((long)gm * p.lda + c * 8) * 2;
-      a2_ptr[i] = p.A2 ? p.A2 + ((long)gm * p.lda2 + a2off + c * 8) * 2 : nullptr;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < B_INSTR; ++i) {
-    const int r = (w + i * NW) * 16 + prow;
-    int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
-    const int c = ppos ^ ((r >> 2) & 3);
-    w_chunk[i] = c;
-    w_ptr[i] = Wp + ((long)gn * p.ldw + c * 8) * 2;
-    w2_ptr[i] = p.W2 ? W2p + ((long)gn * p.ldw2 + c * 8) * 2 : nullptr;
-  }
-  const int Ctot = p.C1 + p.C2;
-  const int cpt = CONV ? Ctot / BK3 : 1;
-  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
-
-  auto issue = [&](int kt) {
-    char* sbase = smem + (kt % NST3) * STAGE_BYTES;
-    const bool s2 = kt >= nk1;
-    const int k0 = (s2 ? kt - nk1 : kt) * BK3;
-    const int Kseg = s2 ? p.K2 : p.K;
-    const bool full = (k0 + BK3) <= Kseg;              // wave-uniform: no per-lane K-tail test needed
-    if constexpr (CONV) {
-      const int tap = kt / cpt; const int cc = kt - tap * cpt;
-      const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
-      int c0 = cc * BK3;
-      const char* xsrc = p.A; int xC = p.C1;
-      if (c0 >= p.C1) { xsrc = p.X2; xC = p.C2; c0 -= p.C1; }
-      const int Hl = p.upsample ? p.Hin * 2 : p.Hin;
-      const int Wl = p.upsample ? p.Win * 2 : p.Win;
-#pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        int iy = cy[i] * p.stride + dy - pad;
-        int ix = cx[i] * p.stride + dx - pad;
-        const bool ok = (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
-        if (p.upsample) { iy >>= 1; ix >>= 1; }
-        const long pix = ((long)cb[i] * p.Hin + iy) * p.Win + ix;
-        const char* asrc = ok ? xsrc + (pix * xC + c0 + a_chunk[i] * 8) * 2 : zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < B_INSTR; ++i) {
-        const char* wsrc = w_ptr[i] + (long)kt * (BK3 * 2);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        const char* asrc = (s2 ? a2_ptr[i] : a_ptr[i]) + k0 * 2;
-        if (!full && (k0 + a_chunk[i] * 8) >= Kseg) asrc = zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < B_INSTR; ++i) {
-        const char* wsrc = (s2 ? w2_ptr[i] : w_ptr[i]) + k0 * 2;
-        if (!full && (k0 + w_chunk[i] * 8) >= Kseg) wsrc = zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  const int wm = w / WN_, wn = w % WN_;
-  f32x16 acc[MT][NT];
-  acc_init_cols<T, MT, NT>(p, acc, lane & 31, n0 + wn * (NT * 32), m0);
-  using V8 = typename Vec<T>::v8;
-
-  // stage-relative fragment offsets (ks = 0/1 differ by chunk ^ 2 -> precompute both)
-  int aro[MT][2], bro[NT][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int kc = ks * 2 + hi;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int ra = wm * (MT * 32) + i * 32 + l31;
-      aro[i][ks] = ra * 64 + ((kc ^ ((ra >> 2) & 3)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int rb = wn * 64 + j * 32 + l31;
-      bro[j][ks] = A_BYTES + rb * 64 + ((kc ^ ((rb >> 2) & 3)) << 4);
-    }
-  }
-
-#pragma unroll
-  for (int s = 0; s < NST3 - 1; ++s)
-    if (s < nk) issue(s);
-
-  if constexpr (STAG) {
-    // Staggered main loop (8-wave configurations).  Waves w and w+4 share a SIMD; all 8 meet at ONE barrier per stage,
-    // but the upper four run half a stage behind: after barrier k the lower group ISSUES (DMA for stage k+3, the 12
-    // fragment reads of stage k) and then computes stage k, while the upper group first computes stage k-1 from the
-    // fragments it read last time and only then issues/reads.  On every SIMD one wave is therefore in its 16-MFMA
-    // section while its partner is in its load section, instead of both hitting the LDS/DMA path and then the matrix
-    // pipe together (the lock-step structure measured 43 % MFMA-busy with 37 % of wave time in s_waitcnt/barrier).
-    // Hazards: stage k's buffer is read by both groups between barrier k and k+1; the DMA issued after barrier k
-    // targets buffer (k+3)%4 = (k-1)%4, last read before barrier k by both groups.
-    const bool late = w >= NW / 2;
-    V8 af[2][MT], bf[2][NT];
-    auto mma = [&]() {
-      if (p.dbg & 8) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
-      if (p.dbg & 8) __builtin_amdgcn_s_setprio(0);
-    };
-    const bool prof = (p.dbg & 16) && blockIdx.x == 0;
-    long long c_wait = 0, c_bar = 0, c_mma = 0, c_dma = 0, c_rd = 0, t0 = 0, t1;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int ahead = nk - 1 - kt;
-      if (prof) t0 = __builtin_readcyclecounter();
-      if (NST3 >= 4 && ahead >= 2) wait_vmcnt<2 * NDMA>();
-      else if (ahead >= 1) wait_vmcnt<NDMA>();
-      else wait_vmcnt<0>();
-      if (prof) { t1 = __builtin_readcyclecounter(); c_wait += t1 - t0; t0 = t1; }
-      __builtin_amdgcn_s_barrier();
-      if (prof) { t1 = __builtin_readcyclecounter(); c_bar += t1 - t0; t0 = t1; }
-      if (late && kt > 0) mma();
-      if (prof) { asm volatile("s_nop 0" ::: "memory"); t1 = __builtin_readcyclecounter(); if (late) c_mma += t1 - t0; t0 = t1; }
-      if (kt + NST3 - 1 < nk) issue(kt + NST3 - 1);
-      if (prof) { t1 = __builtin_readcyclecounter(); c_dma += t1 - t0; t0 = t1; }
-      const char* sb = smem + (kt % NST3) * STAGE_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[ks][j] = *(const V8*)(sb + bro[j][ks]);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)(sb + aro[i][ks]);
-      }
-      if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t1 = __builtin_readcyclecounter(); c_rd += t1 - t0; t0 = t1; }
-      if (!late) mma();
-      if (prof) { asm volatile("s_nop 0" ::: "memory"); t1 = __builtin_readcyclecounter(); if (!late) c_mma += t1 - t0; }
-    }
-    if (late) mma();
-    if (prof && lane == 0) {
-      omg_dbg_cycles[w][0] = c_wait; omg_dbg_cycles[w][1] = c_bar; omg_dbg_cycles[w][2] = c_mma; omg_dbg_cycles[w][3] = c_dma;
-      omg_dbg_cycles[w][4] = c_rd; omg_dbg_cycles[w][5] = nk;
-    }
-  } else {
-  // Main loop: counted wait for stage kt, ONE barrier, DMA three stages ahead, then 2 k-steps of MFMAs.
-    // (A variant with the barrier between the two k-steps and fragment reads issued one k-step ahead measured
-    //  2-5 % slower on MI355X: the compiler already overlaps the second k-step's ds_reads with the first's MFMAs.)
-    for (int kt = 0; kt < nk; ++kt) {
-      const int ahead = nk - 1 - kt;         // later stages whose DMA may stay in flight: min(ahead, NST3 - 2)
-      if (!(p.dbg & 2)) {
-        if (NST3 >= 4 && ahead >= 2) wait_vmcnt<2 * NDMA>();
-        else if (ahead >= 1) wait_vmcnt<NDMA>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-      }
-      if (kt + NST3 - 1 < nk && !(p.dbg & 1)) issue(kt + NST3 - 1);
-      const char* sb = smem + (kt % NST3) * STAGE_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        V8 af[MT], bf[NT];
-        if (!(p.dbg & 4) || kt == 0) {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bf[j] = *(const V8*)(sb + bro[j][ks]);
-#pragma unroll
-          for (int i = 0; i < MT; ++i) af[i] = *(const V8*)(sb + aro[i][ks]);
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[i], bf[j], acc[i][j]);
-      }
-    }
-  }
-  __syncthreads();
-  epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
-}
-
 // ------------------------------------------------------------------------------------------------
-// v5: BK = 64 double-buffered large-tile kernel.  Phase timing of v3 (tools/gemm_phases.py) shows the 4 LDS-DMA
-// instructions of a BK=32 stage cost ~650 cycles per wave against 512 cycles of MFMA: a 64-byte row is half a cache
-// line, so every DMA instruction touches 16 lines for 1 KiB.  With 128-byte rows each instruction moves 8 WHOLE lines.
+// v5: BK = 64 double-buffered large-tile kernel (the fallback of v6/v7 for the LoRA second K-segment and K % 64 != 0).
+// Its predecessor used a 4-deep ring of BK = 32 stages; phase timing showed the 4 LDS-DMA instructions of such a stage cost
+// ~650 cycles per wave against 512 cycles of MFMA: a 64-byte row is half a cache line, so every DMA instruction touched 16
+// lines for 1 KiB.  With 128-byte rows each instruction moves 8 WHOLE lines.
 template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
 __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
-  constexpr int NST3 = 2;
-  constexpr int BK3 = 64;          // shadows the 32-wide constant: 128-byte rows = whole cache lines per DMA row
+  constexpr int BK3 = 64;          // 128-byte rows = whole cache lines per DMA row
   constexpr int NW = WM_ * WN_;
   constexpr int MT = BM_ / WM_ / 32;             // 32-row MFMA tiles per wave (2 or 4)
   constexpr int NT = BN_ / WN_ / 32;             // must be 2
@@ -911,7 +645,6 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
   constexpr int A_INSTR = BM_ / 8 / NW;          // one DMA instruction = 8 rows x 128 B
   constexpr int B_INSTR = BN_ / 8 / NW;
   static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
-  constexpr int NDMA = A_INSTR + B_INSTR;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -1837,34 +1570,9 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v8(GemmP p) {
 #undef OMG_STAGE
 }
 
-constexpr int lds_bytes_v3(int bm, int bn, int nw, int nst) {
-  const int ring = nst * (bm + bn) * BK3 * 2;
-  const int epi = nw * 32 * STAGE_LD * 4;
-  return ring > epi ? ring : epi;
-}
-
-
-
 bool g_use_glds = true;
 int g_dbg = 0;
-int g_variant = 0;   // 0 = heuristic, 1 = 128x128 v1, 3 = 256x256, 4 = 256x128
-
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_, int NST_, bool STAG_ = false>
-int launch_v3(GemmP p, hipStream_t s, int mrows) {
-  constexpr int lds = lds_bytes_v3(BM_, BN_, WM_ * WN_, NST_);
-  static bool attr = false;
-  if (!attr) {
-    attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_, STAG_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
-  p.tiles_m = (mrows + BM_ - 1) / BM_;
-  p.tiles_n = (p.N + BN_ - 1) / BN_;
-  p.dbg = g_dbg;
-  const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
-  if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v3<T, CONV, BM_, BN_, WM_, WN_, NST_, STAG_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
-  return omg_check_launch("gemm_v3");
-}
+int g_variant = 0;   // 0 = heuristic; 1 = 128x128 v1; 11/12 = v5 256x256 / 256x128; 13/14 = v6; 15 = v7 256x256; 16 = v8; 24 = v7 128x320
 
 template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
 int launch_v5(GemmP p, hipStream_t s, int mrows) {
@@ -1976,8 +1684,6 @@ int launch(const GemmP& p, hipStream_t s) {
   const int mrows = p.tile_groups > 1 ? p.rows_per_group : p.M;
   if (g_use_glds) {
     int v = choose_variant(mrows, p.tile_groups, p.N, CONV);
-    if (v == 3) return launch_v3<T, CONV, 256, 256, 2, 4, 4>(p, s, mrows);
-    if (v == 4) return launch_v3<T, CONV, 256, 128, 4, 2, 4>(p, s, mrows);
     // v6 (interleaved DMA) handles everything except the LoRA second K-segment and > 2 GiB operands
     const long lim = 0x7fff0000L;
     const long a_sz = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 : (long)p.M * p.lda * 2;
@@ -2004,10 +1710,6 @@ int launch(const GemmP& p, hipStream_t s) {
     if (v == 13 || v == 14) { if (v6ok) return v == 13 ? launch_v6<T, CONV, 4>(p, s, mrows) : launch_v6<T, CONV, 2>(p, s, mrows); v = (v == 13) ? 11 : 12; }
     if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
     if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);
-    if (v == 9) return launch_v3<T, CONV, 256, 256, 2, 4, 4, true>(p, s, mrows);
-    if (v == 10) return launch_v3<T, CONV, 256, 128, 4, 2, 4, true>(p, s, mrows);
-    if (v == 5) return launch_v3<T, CONV, 256, 128, 2, 2, 3>(p, s, mrows);   // 4 waves x (128x64), 72 KiB: 2 blocks/CU
-    if (v == 6) return launch_v3<T, CONV, 128, 256, 1, 4, 3>(p, s, mrows);
   }
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
@@ -2038,9 +1740,6 @@ void ensure_attrs() {
 
 extern "C" int omg_debug_read_ts(long long* out, int blocks) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(omg_dbg_ts), sizeof(long long) * 6 * (blocks < 8192 ? blocks : 8192));
-}
-extern "C" int omg_debug_read_cycles(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(omg_dbg_cycles), sizeof(long long) * 64);
 }
 extern "C" void omg_debug_set_glds(int on) { g_use_glds = on != 0; }
 extern "C" void omg_debug_set_gemm_variant(int v) { g_variant = v & 0xff; g_dbg = v >> 8; }
