@@ -202,7 +202,7 @@ def main():
                 f.write(f"# per bench step ({ips} images): kind, shape tag, launches, ms, share, TF/s; total {tot:.1f} ms\n")
                 for key, ms, fl, n in rows:
                     f.write(f"{key[0]:5s} {str(key[1]):56s} n={n:7.0f} ms={ms:9.2f} ({100 * ms / tot:4.1f}%) {fl / ms / 1e9 if ms else 0:7.1f} TF/s\n")
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the host-core baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out))
