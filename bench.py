@@ -184,8 +184,21 @@ def main():
         g_ms, g_fl, g_n = comb("gemm", "ms"), comb("gemm", "flops"), comb("gemm", "launches")
         a_ms, a_fl = comb("attn", "ms"), comb("attn", "flops")
         ach = g_fl / (g_ms * 1e-3) / 1e12
+        # HBM-side bytes cannot be counted from inside this process: the committed rocprofv3 --pmc measurement of the
+        # dominant GEMM shape (profiles/r01_pmc_traffic.json, method and gfx950 correction recorded there) is reported
+        traffic, traffic_note = None, "no PMC measurement committed"
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pm = json.load(f)
+            traffic = pm["traffic_bytes_per_launch"]
+            traffic_note = ("bytes per launch of the largest GEMM (M 65536, N 10240, K 1280; %.2f GB algorithmic) from rocprofv3 --pmc "
+                            "FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes: profiles/r01_pmc_traffic.json"
+                            % ((pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"]) / 1e9))
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_v7 / gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)",
-                           "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": None,
+                           "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": traffic,
+                           "traffic_note": traffic_note,
                            "launches_per_step": g_n, "avg_launch_us": 1e3 * g_ms / g_n, "avg_launch_gflop": g_fl / g_n / 1e9,
                            "gemm_ms_per_step": g_ms,
                            "sample": f"HIP events around each launch (eager), 2 plain + 2 fused denoising steps weighted {n_p}:{n_f} as in the timed workload",
