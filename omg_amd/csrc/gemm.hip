@@ -451,9 +451,9 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
 template <typename T>
 OMG_DEV void swap_runs(unsigned (&q)[4]) {   // q[0..1] = run 0 (4 halves), q[2..3] = run 1
   // v_permlane32_swap v_a, v_b exchanges lanes 32-63 of v_a with lanes 0-31 of v_b (both operands are written).
-  // Inline asm with wait states on both sides, tied to the four registers by data dependence: with the builtin and the
-  // compiler's own hazard nops, lanes 12-15 / 28-31 of each half intermittently saw a stale third dword when the
-  // producer (v_cvt_pk_f16_f32) or the consumer (buffer_store) sat right next to the swap (tools/debug_gemm_small.py).
+  // Kept as inline asm with wait states on both sides, tied to the four registers by data dependence, so that neither the
+  // producer (v_cvt_pk_f16_f32) nor the consumer (buffer_store) can be scheduled against an instruction that writes both of
+  // its operands.  (The corruption first suspected here turned out to be the store-data hazard described in store_runs.)
   asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 4"
                : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
 }
