@@ -92,6 +92,7 @@ SYMBOLS = {
     "omg_attn_apply_probs": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
     "omg_debug_set_glds": (None, [c_i32]),
     "omg_debug_set_gemm_variant": (None, [c_i32]),
+    "omg_debug_choose_variant": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
 }
 
 _lib = None

@@ -1743,6 +1743,14 @@ extern "C" int omg_debug_read_ts(long long* out, int blocks) {
 }
 extern "C" void omg_debug_set_glds(int on) { g_use_glds = on != 0; }
 extern "C" void omg_debug_set_gemm_variant(int v) { g_variant = v & 0xff; g_dbg = v >> 8; }
+// host-only: the tile variant the cost model picks for (rows per group, groups, N, conv) — lets the CPU tests pin the table
+extern "C" int omg_debug_choose_variant(int mrows, int groups, int N, int conv) {
+  const int saved = g_variant;
+  g_variant = 0;
+  const int v = choose_variant(mrows, groups, N, conv != 0);
+  g_variant = saved;
+  return v;
+}
 
 extern "C" int omg_gemm(const omg_gemm_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_gemm: null args");
