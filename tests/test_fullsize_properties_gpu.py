@@ -1,0 +1,111 @@
+"""Size-independent properties at BASELINE's full sizes (SDXL widths, 1024x1024 images, 4096 / 1024 tokens), where the
+CPU oracle would take minutes per sample: exact algebraic identities of the kernels, checked bitwise where the identity
+is exact in floating point (power-of-two scaling, row / channel permutations, batching) and to 16-bit rounding otherwise."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from omg_amd import _lib as L
+from omg_amd import ops
+from omg_amd.unet import UNet2DConditionModel, UNetConfig
+
+
+def rnd(*shape, dev, dtype=torch.float16, scale=1.0, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=dev) * scale).to(dtype)
+
+
+def test_gemm_scaling_and_row_permutation_are_exact(dev):
+    """FF-GEGLU / QKV sized GEMMs: out(2a) == 2 out(a) and out(a[perm]) == out(a)[perm], bit for bit (a row's dot products do
+    not depend on which tile, wave or lane computes them)."""
+    for (M, N, K) in [(8192, 10240, 1280), (16384, 1920, 640)]:
+        # operands on a binary grid well above the fp16 subnormal range (the MFMA flushes subnormal inputs, which would break
+        # exact scaling for the few values below 6.1e-5)
+        g = torch.Generator(device=dev).manual_seed(1)
+        a = (torch.randint(-2048, 2049, (M, K), generator=g, device=dev).float() / 512).half()
+        w = (torch.randint(-64, 65, (N, K), generator=g, device=dev).float() / 1024).half()
+        b = rnd(N, dev=dev, seed=3)
+        y = ops.gemm(a, w)
+        assert torch.equal(ops.gemm(a * 2, w), y * 2)
+        perm = torch.randperm(M, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+        assert torch.equal(ops.gemm(a[perm].contiguous(), w, bias=b), ops.gemm(a, w, bias=b)[perm])
+        # additivity over a K split holds to fp32-accumulate / 16-bit-store rounding
+        y2 = ops.gemm(a[:, : K // 2], w[:, : K // 2]).float() + ops.gemm(a[:, K // 2:], w[:, K // 2:]).float()
+        assert (y.float() - y2).abs().max() < 2e-2
+
+
+def test_conv_batching_and_output_channel_permutation_are_exact(dev):
+    """3x3 conv at the 128x128 / 64x64 feature-map sizes: batching samples and permuting output channels commute with the
+    kernel bitwise, although the batched call runs on a different tile variant."""
+    for (H, C, Co) in [(128, 320, 320), (64, 640, 640)]:
+        x = rnd(2, H, H, C, dev=dev, seed=5)
+        w = rnd(Co, 9 * C, dev=dev, scale=(9 * C) ** -0.5, seed=6)
+        b = rnd(Co, dev=dev, seed=7)
+        y = ops.conv2d(x, w, 3, bias=b)
+        assert torch.equal(y[0:1], ops.conv2d(x[0:1].contiguous(), w, 3, bias=b))
+        perm = torch.randperm(Co, device=dev, generator=torch.Generator(device=dev).manual_seed(8))
+        assert torch.equal(ops.conv2d(x, w[perm].contiguous(), 3, bias=b[perm].contiguous()), y[..., perm])
+        # a constant input: every interior output pixel of a channel is the same number
+        ones = torch.ones(1, H, H, C, device=dev, dtype=torch.float16)
+        yc = ops.conv2d(ones, w, 3, bias=b)[0, 1:-1, 1:-1]
+        assert torch.equal(yc, yc[0:1, 0:1].expand_as(yc))
+
+
+def test_attention_rows_sum_to_one_and_ignore_key_order(dev):
+    """Self-attention at 64x64 tokens (10 heads) and 32x32 (20 heads): with V = 1 the output is 1; permuting the keys together
+    with their values changes nothing beyond rounding; borrowing Q,K (the p2p replacement) reproduces the source sample."""
+    for (heads, N) in [(10, 4096), (20, 1024)]:
+        C = heads * 64
+        q, k, v = rnd(2, N, C, dev=dev, seed=9), rnd(2, N, C, dev=dev, seed=10), rnd(2, N, C, dev=dev, seed=11)
+        ones = torch.ones_like(v)
+        o1 = ops.attention(q, k, ops.transpose_v(ones, heads), heads, 0.125)
+        assert (o1.float() - 1).abs().max() < 2e-3
+        o = ops.attention(q, k, ops.transpose_v(v, heads), heads, 0.125)
+        perm = torch.randperm(N, device=dev, generator=torch.Generator(device=dev).manual_seed(12))
+        op = ops.attention(q, k[:, perm].contiguous(), ops.transpose_v(v[:, perm].contiguous(), heads), heads, 0.125)
+        assert (o.float() - op.float()).abs().max() < 4e-3
+        src = torch.tensor([0, 0], dtype=torch.int32, device=dev)          # sample 1 borrows Q,K of sample 0, keeps its own V
+        v2 = torch.stack([v[0], v[0]])
+        ob = ops.attention(q, k, ops.transpose_v(v2, heads), heads, 0.125, qk_src=src)
+        assert torch.equal(ob[1], ob[0]) and torch.equal(ob[0], o[0])
+
+
+def test_fused_step_with_empty_masks_is_the_plain_step(dev):
+    """Masked fusion + CFG + DDIM step at the 128x128 latent: all-zero region masks leave the edit noise untouched, so the
+    fused launch must equal the plain one bitwise."""
+    g = torch.Generator(device=dev).manual_seed(13)
+    noise = torch.randn(4, 4, 128, 128, generator=g, device=dev)
+    lat0 = torch.randn(2, 4, 128, 128, generator=g, device=dev)
+    region = [torch.randn(2, 4, 128, 128, generator=g, device=dev) for _ in range(2)]
+    masks = [torch.zeros(1024, 1024, device=dev) for _ in range(2)]
+    coef = torch.tensor([[0.99, -0.05, 1.0, 0.0]] * 4, device=dev)
+    outs = []
+    for fuse in (False, True):
+        lat, nxt = lat0.clone(), torch.empty(4, 4, 128, 128, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.fuse_cfg_step(noise.clone(), lat, coef, step, guidance_scale=7.5, fuse=fuse, region_preds=region if fuse else (),
+                          masks=masks if fuse else (), model_input_next=nxt)
+        outs.append((lat, nxt, step.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and int(outs[1][2]) == 1
+
+
+def test_sdxl_unet_is_batch_invariant_at_full_size(dev):
+    """The full 2.57 B-parameter UNet on 1024x1024 latents: a batch of two equals the two samples run alone, bitwise."""
+    dtype = torch.float16
+    cfg = UNetConfig.sdxl()
+    unet = UNet2DConditionModel(cfg, dtype=dtype, device=dev).init_synthetic_(seed=0)
+    assert sum(p.numel() for p in unet.parameters()) == 2_567_463_684
+    Ls = cfg.sample_size
+    x = rnd(2, 4, Ls, Ls, dev=dev, dtype=torch.float32, seed=14)
+    ctx = rnd(2, 77, cfg.cross_attention_dim, dev=dev, seed=15)
+    te = rnd(2, 1280, dev=dev, seed=16)
+    tid = torch.tensor([[1024.0, 1024.0, 0, 0, 1024.0, 1024.0]] * 2, device=dev)
+
+    def fwd(i0, i1):
+        return unet(x[i0:i1], 981, encoder_hidden_states=ctx[i0:i1].contiguous(),
+                    added_cond_kwargs={"text_embeds": te[i0:i1].contiguous(), "time_ids": tid[i0:i1]}, return_dict=False)[0]
+
+    both = fwd(0, 2)
+    assert both.shape == (2, 4, Ls, Ls) and torch.isfinite(both).all()
+    assert torch.equal(both[0:1], fwd(0, 1)) and torch.equal(both[1:2], fwd(1, 2))
