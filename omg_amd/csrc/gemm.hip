@@ -7,20 +7,24 @@
 // never straddles a tap).  Activations are NHWC, so the conv A-operand row for
 // output pixel (b,y,x) and tap (dy,dx) is 128 contiguous bytes of the input.
 //
-// Structure (v1): 128x128x64 block tile, 256 threads = 4 wave64 in 2x2, each wave
-// 64x64 = 2x2 tiles of v_mfma_f32_32x32x16.  Tiles are staged global->LDS with
-// LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) into a
-// double-buffered, XOR-swizzled image: the DMA destination is lane-linear, so the
-// swizzle is applied to the per-lane SOURCE chunk and again on the ds_read_b128
-// (cdna guide §5.4 rule 21).  Out-of-image taps and the K tail read a global zero
-// page instead of branching.  The epilogue stages the fp32 accumulators through
-// LDS so that bias/residual loads and the output stores are 16 B per lane on whole
-// 128-byte row segments.
+// Kernels in this file (chosen per launch by choose_variant; every one produces the same bits for the same problem):
+//   v1 (gemm_kernel)      128x128x64 tile, 4 waves of 64x64, two blocks per CU — small launches, narrow outputs.
+//   v5 (gemm_kernel_v5)   256x{256,128}x64, 8 waves in two staggered groups — fallback for the LoRA second K-segment.
+//   v6 (gemm_kernel_v6)   same tiles, LDS-DMA issued between MFMA quartets through buffer descriptors; 256x128 in use.
+//   v7 (gemm_kernel_v7)   256x256 (and 128x320 for the convs of width 320 k) on FOUR waves, 128x128 per wave, K loop
+//                         software-pipelined inside the wave, one barrier per stage — the workhorse (>= 70 % of the time).
+//   v8 (gemm_kernel_v8)   v7 as a persistent kernel (debug variant 16, not selected yet).
+// Common to all: v_mfma_f32_32x32x16, tiles staged global->LDS with LDS-DMA (1 KiB per wave instruction) into a
+// double-buffered, XOR-swizzled image — the DMA destination is lane-linear, so the swizzle is applied to the per-lane
+// SOURCE chunk and again on the ds_read_b128 (cdna guide §5.4 rule 21); out-of-image taps and the K tail read zeros
+// (a global zero page in v1/v5, out-of-range buffer offsets in v6-v8).  v1/v5 stage the fp32 accumulators through LDS for
+// row-coalesced stores; v6-v8 accumulate the transposed tile and store 16 bytes per lane straight from registers
+// (epilogue_direct).  Measurements and the rejected alternatives: DESIGN.md §5.
 #include "common.h"
 
 __device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
 
-__device__ long long omg_dbg_ts[8192][6];   // tools only: per-block timestamps (dbg bit 16): start, stage 0 landed, loop end, epilogue issued, HW_ID, XCC_ID   // tools only: per-wave phase cycle totals of block 0 (dbg bit 16)
+__device__ long long omg_dbg_ts[8192][6];   // tools only (dbg bit 16): per-block timestamps: start, stage 0 landed, loop end, epilogue issued, HW_ID, XCC_ID
 
 namespace {
 
