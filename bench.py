@@ -219,6 +219,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out))
+    if world > 1:          # orderly shutdown: the other ranks wait for rank 0's instrumented passes, then RCCL is torn down
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def _quiet(fn, *a):
