@@ -174,3 +174,24 @@ def test_controlnet_topology_parameter_count():
         n += k
     assert n == 1_251_014_160        # SDXL ControlNet: encoder copy of the UNet + conditioning embedding + 10 zero convs
     assert len([k for k in ocn.param_shapes(ounet.UNetConfig.sdxl()) if k.startswith("controlnet_down_blocks.") and k.endswith(".weight")]) == 9
+
+
+# ------------------------------------------------------------------ VAE decoder oracle (row N1) — anchors available without a GPU
+def test_vae_oracle_topology_and_key_layout():
+    import math
+    from oracle import vae as ov
+    from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
+    shapes = ov.param_shapes(ov.VaeConfig.sdxl())
+    assert sum(math.prod(s) for k, s in shapes.items() if k.startswith("decoder.")) == 49_490_179      # SDXL VAE decoder
+    assert sum(math.prod(s) for k, s in shapes.items() if k.startswith("post_quant_conv.")) == 20
+    prod = AutoencoderKLDecoder(VaeConfig.sdxl(), dtype=torch.float16, device="meta")
+    assert {k: tuple(v.shape) for k, v in prod.state_dict().items()} == shapes                        # diffusers' key layout, both sides
+    cfg = ov.VaeConfig.tiny()
+    sd = ov.init_state_dict(cfg, seed=0)
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0))
+    taps = {}
+    img = ov.decode(sd, cfg, z, taps)
+    assert img.shape == (2, 3, 16, 16) and torch.isfinite(img).all() and set(taps) == {"mid", "up0", "up1"}
+    # batch-independent (torch-CPU picks different conv algorithms per batch size, so to rounding, not bitwise)
+    torch.testing.assert_close(ov.decode(sd, cfg, z[:1]), img[:1], rtol=1e-5, atol=1e-5)
+    assert float(ov.postprocess(img).min()) >= 0.0 and float(ov.postprocess(img).max()) <= 1.0
