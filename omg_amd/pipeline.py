@@ -7,11 +7,11 @@ same keyword names and meaning for everything on the hot path (``num_inference_s
 layout: latents duplicated x2 (:409), model input ``[unc0, unc1, cond0, cond1]`` (:467-474, :491), concept
 pass on ``latent_model_input[3:4]`` duplicated (:583-585), fusion for ``i > 15 and stage == 2`` (:568).
 
-What is NOT here (row N4 of SURVEY §8f): the text encoders.  The call therefore takes ``prompt_embeds`` / pooled
-embeddings (the reference computes them at :315-347 and passes them on) and returns latents
+Text encoders and the VAE are separate modules (rows N4 / N1 of SURVEY §8f).  Without them the call takes ``prompt_embeds`` /
+pooled embeddings (the reference computes them at :315-347 and passes them on) and returns latents
 (``output_type="latent"``), or decoded images in [0, 1] when the pipeline was built with
 ``vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents`` (row N1; the reference's tail at :635-661);
-``prompt=`` works only if the caller supplies an ``encode_prompt`` callable.
+``prompt=`` works when the pipeline was built with ``encode_prompt=omg_amd.text_encoder.make_encode_prompt(...)``.
 
 MI355X-first differences from the reference's loop, all value-preserving:
   * the K per-concept UNet passes of a step run as ONE batched forward with a per-sample LoRA slot;
@@ -184,8 +184,8 @@ class LoraMultiConceptPipeline:
         # ---- 3. prompt embeddings (global on the main pipe; per-region on the concept pipe)
         if prompt_embeds is None:
             if self.encode_prompt is None:
-                raise L.OmgHipError("text encoders are outside this package's scope: pass prompt_embeds=/pooled_prompt_embeds= "
-                                    "(and region_prompt_embeds=) or construct the pipeline with encode_prompt=")
+                raise L.OmgHipError("no text encoders attached: pass prompt_embeds=/pooled_prompt_embeds= (and region_prompt_embeds=) or "
+                                    "construct the pipeline with encode_prompt=omg_amd.text_encoder.make_encode_prompt(...)")
             global_prompt, regions = prompt[0], prompt[1]
             prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = self.encode_prompt(
                 global_prompt, negative_prompt, None)

@@ -175,3 +175,31 @@ def encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, ids_l: torch.T
     hl, _ = enc_l(ids_l)
     hg, pooled = enc_g(ids_g)
     return torch.cat([hl, hg], dim=-1), pooled
+
+
+def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_l, tokenize_g=None):
+    """The ``encode_prompt=`` callable of :class:`omg_amd.pipeline.LoraMultiConceptPipeline`:
+    ``fn(prompt, negative_prompt, lora_param) -> (prompt_embeds, negative_prompt_embeds, pooled, negative_pooled)`` as diffusers'
+    ``StableDiffusionXLPipeline.encode_prompt`` returns them (lora_pipeline.py:315-347).  ``tokenize_*`` map a list of strings to
+    (B, 77) int64 ids (the reference's ``pipe.tokenizer`` / ``pipe.tokenizer_2`` with ``padding="max_length"``).  A ``None``
+    negative prompt gives zero embeddings (SDXL-base ships ``force_zeros_for_empty_prompt=True``).  ``lora_param`` is accepted
+    and ignored: only the UNet half of a LoRA file is applied on this path (omg_amd/loaders.py)."""
+    tokenize_g = tokenize_g or tokenize_l
+
+    def _list(p, n):
+        out = [p] if isinstance(p, str) else list(p)
+        return out * n if len(out) == 1 and n > 1 else out
+
+    def fn(prompt, negative_prompt=None, lora_param=None):
+        prompts = _list(prompt, 1)
+        dev = enc_l.device
+        pe, pp = encode_prompt(enc_l, enc_g, tokenize_l(prompts).to(dev), tokenize_g(prompts).to(dev))
+        if negative_prompt is None:
+            return pe, torch.zeros_like(pe), pp, torch.zeros_like(pp)
+        negs = _list(negative_prompt, len(prompts))
+        if len(negs) != len(prompts):
+            raise ValueError("negative_prompt must be one string or one per prompt")
+        ne, npp = encode_prompt(enc_l, enc_g, tokenize_l(negs).to(dev), tokenize_g(negs).to(dev))
+        return pe, ne, pp, npp
+
+    return fn

@@ -61,3 +61,26 @@ def test_encode_prompt_concatenates_both_encoders(dev):
     emb, pooled = encode_prompt(enc_l, enc_g, ids, ids)
     assert emb.shape == (2, 77, 256) and pooled.shape == (2, 64) and torch.isfinite(emb).all()
     assert torch.equal(emb[..., :128], enc_l(ids)[0])
+
+
+def test_make_encode_prompt_contract(dev):
+    from omg_amd.text_encoder import make_encode_prompt
+    _, _, enc_l = _pair("quick_gelu", False, dev, torch.float16, seed=2)
+    _, _, enc_g = _pair("gelu", True, dev, torch.float16, seed=3)
+
+    def tok(texts):                                      # stand-in for the CLIP tokenizer: bos, one id per word, eos padding
+        out = torch.full((len(texts), 77), 299, dtype=torch.long)
+        out[:, 0] = 298
+        for b, t in enumerate(texts):
+            for i, w in enumerate(t.split()[:75]):
+                out[b, 1 + i] = 2 + sum(map(ord, w)) % 296
+        return out
+
+    fn = make_encode_prompt(enc_l, enc_g, tok)
+    pe, ne, pp, npp = fn(["a man and a woman", "a man and a woman"], "blurry", None)
+    assert pe.shape == ne.shape == (2, 77, 256) and pp.shape == npp.shape == (2, 64)
+    assert torch.equal(pe[0], pe[1]) and torch.equal(ne[0], ne[1]) and not torch.equal(pe, ne)
+    ids = tok(["a man and a woman"]).to(dev)
+    assert torch.equal(pe[:1], encode_prompt(enc_l, enc_g, ids, ids)[0])
+    pe2, ne2, pp2, npp2 = fn("a man and a woman")
+    assert torch.equal(pe2, pe[:1]) and float(ne2.abs().max()) == 0.0 and float(npp2.abs().max()) == 0.0
