@@ -500,7 +500,9 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
     MAIN pass, :574-616) = ``controlnet2``; the concept UNet's IP-Adapter processors (instantid_single_pieline.py:186-213) = an
     :class:`omg_amd.ip_adapter.IPAdapter` installed on the shared UNet.  Face detection / ArcFace embedding (``face_app``) and the
     Resampler that turns a 512-d embedding into 16 tokens run once per image outside the hot path: pass the
-    resulting tokens as ``region_image_embeds`` = [(2, 16, Cx) = [tokens of the zero embedding, tokens of the identity]] per concept."""
+    resulting tokens as ``region_image_embeds`` = [(2, 16, Cx) = [tokens of the zero embedding, tokens of the identity]] per concept
+    (:class:`omg_amd.resampler.Resampler` computes them from the embedding: ``resampler(torch.stack([zeros, emb]).view(2, 1, 512))``,
+    instantid_single_pieline.py:221-243)."""
 
     def __init__(self, unet, identitynet, scheduler=None, controlnet2=None, **kw):
         super().__init__(unet, scheduler, **kw)

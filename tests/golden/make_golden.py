@@ -26,6 +26,7 @@ from oracle.controller import PieceTokenizer, WhitespaceTokenizer  # tokenizers 
 from src.prompt_attention.p2p_attention import AttentionReplace  # noqa: E402  (reference code)
 from src.prompt_attention import seq_aligner  # noqa: E402
 from src.ip_adapter.attention_processor import IPAttnProcessor2_0, AttnProcessor2_0  # noqa: E402
+from src.ip_adapter.resampler import Resampler  # noqa: E402
 
 
 def controller_vectors():
@@ -134,6 +135,26 @@ def ip_adapter_vectors():
     print("ip_adapter_golden.npz:", len(out), "arrays")
 
 
+def resampler_vectors():
+    """The reference's own Resampler (InstantID image_proj_model topology at reduced width) on seeded weights."""
+    torch.manual_seed(21)
+    m = Resampler(dim=64, depth=2, dim_head=32, heads=2, num_queries=8, embedding_dim=32, output_dim=48, ff_mult=4).eval()
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if n.endswith("bias"):
+                p_.copy_(0.1 * torch.randn_like(p_))
+            elif "norm" in n or n.endswith(".0.weight"):
+                p_.copy_(1.0 + 0.1 * torch.randn_like(p_))
+        x = torch.randn(3, 2, 32)
+        y = m(x)
+    out = {"cfg": np.array([64, 2, 32, 2, 8, 32, 48, 4]), "x": x.numpy(), "y": y.numpy()}
+    for k, v in m.state_dict().items():
+        out["sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "resampler_golden.npz"), **out)
+    print("resampler_golden.npz", {k: v.shape for k, v in out.items() if not k.startswith("sd.")})
+
+
 if __name__ == "__main__":
     controller_vectors()
     ip_adapter_vectors()
+    resampler_vectors()

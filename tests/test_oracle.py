@@ -195,3 +195,17 @@ def test_vae_oracle_topology_and_key_layout():
     # batch-independent (torch-CPU picks different conv algorithms per batch size, so to rounding, not bitwise)
     torch.testing.assert_close(ov.decode(sd, cfg, z[:1]), img[:1], rtol=1e-5, atol=1e-5)
     assert float(ov.postprocess(img).min()) >= 0.0 and float(ov.postprocess(img).max()) <= 1.0
+
+
+# ------------------------------------------------------------------ Resampler (InstantID image_proj_model) — pinned by the reference's own class
+def test_resampler_oracle_matches_reference_golden():
+    from oracle import resampler as orr
+    g = np.load(os.path.join(GOLD, "resampler_golden.npz"))
+    dim, depth, dim_head, heads, nq, emb, outd, mult = (int(v) for v in g["cfg"])
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    assert {k: tuple(v.shape) for k, v in sd.items()} == orr.param_shapes(dim, depth, dim_head, heads, nq, emb, outd, mult)
+    y = orr.resampler_forward(sd, torch.from_numpy(g["x"]), heads)
+    torch.testing.assert_close(y, torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-5)
+    # InstantID's configuration (instantid_single_pieline.py:165-174): 16 tokens of 2048 from one 512-d embedding
+    full = orr.param_shapes(1280, 4, 64, 20, 16, 512, 2048, 4)
+    assert full["latents"] == (1, 16, 1280) and full["proj_out.weight"] == (2048, 1280) and full["layers.3.1.3.weight"] == (1280, 5120)
