@@ -28,7 +28,7 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
-from .modules import Dropout, Linear, LoraState
+from .modules import Dropout, Linear, LoraState, bump_pointer_epoch, pointer_epoch  # noqa: F401
 
 
 class Attention(nn.Module):
@@ -99,6 +99,8 @@ class Attention(nn.Module):
     def invalidate_packed(self):
         self._qkv = self._kv = self._qkv_slots = self._kv_slots = None
         self._kv_cache = {}
+        self._ip_cache = None
+        bump_pointer_epoch()
 
     def qkv_weight(self) -> torch.Tensor:
         if self._qkv is None:
@@ -111,12 +113,20 @@ class Attention(nn.Module):
         return self._kv
 
     def _has_lora(self) -> bool:
+        """Segment mode with an adapter on ANY of to_q / to_k / to_v: the projections then run as separate GEMMs, each adding
+        its own second K-segment (a projection without adapter weights simply has none)."""
         st = self.to_q.lora_state
-        return st is not None and not st.merged and self.to_q.lora_down is not None
+        return st is not None and not st.merged and any(l.lora_down is not None for l in (self.to_q, self.to_k, self.to_v))
 
     def _merged(self) -> Optional[LoraState]:
+        """Merged mode: LoraBank.build gives all three projections a ``w_slots`` stack as soon as one of them is targeted."""
         st = self.to_q.lora_state
-        return st if (st is not None and st.merged and self.to_q.w_slots is not None) else None
+        if st is None or not st.merged:
+            return None
+        have = [l.w_slots is not None for l in (self.to_q, self.to_k, self.to_v)]
+        if any(have) and not all(have):
+            raise L.OmgHipError("merged LoRA slots cover only part of to_q/to_k/to_v; rebuild the LoraBank")
+        return st if all(have) else None
 
     def qkv_slots(self) -> torch.Tensor:
         if self._qkv_slots is None:
@@ -175,6 +185,7 @@ class Attention(nn.Module):
         vt = ops.transpose_v(v, self.heads, out=vt_out)
         if hit is None and len(self._kv_cache) >= 4:
             self._kv_cache.pop(next(iter(self._kv_cache)))
+            bump_pointer_epoch()                      # a captured graph may still point at the evicted K / V^T
         self._kv_cache[skey] = (stamp, k, vt, ctx, kv_out)
         return k, vt
 

@@ -20,16 +20,36 @@ from . import ops
 from .attention import Attention
 
 
+def attn_processor_index(unet) -> Dict[str, int]:
+    """Attention module name -> its position in diffusers' ``unet.attn_processors`` (attn1 and attn2 both count).
+
+    diffusers' ``UNet2DConditionModel.__init__`` creates ``down_blocks`` and ``up_blocks`` before ``mid_block``, so the
+    processors enumerate down (SDXL: 0-47), up (48-119), mid (120-139) [recalled: diffusers is not installed here]; the
+    ``ip_adapter`` checkpoint is the state dict of ``ModuleList(unet.attn_processors.values())``
+    (instantid_single_pieline.py:208-212), i.e. keyed by exactly this index.  Computed from the block prefixes, not from
+    this package's own module registration order."""
+    rank = {"down_blocks": 0, "up_blocks": 1, "mid_block": 2}
+    names = [name for name, _ in unet.attentions()]
+    order = sorted(range(len(names)), key=lambda i: (rank[names[i].split(".")[0]], i))
+    return {names[i]: pos for pos, i in enumerate(order)}
+
+
 class IPAdapter:
     def __init__(self, unet, num_tokens: int = 16, scale: float = 0.5):
         self.unet, self.num_tokens, self.scale = unet, num_tokens, scale
-        self.layers = []            # (index in attn_processors order, module name, Attention)
-        for idx, (name, m) in enumerate(unet.attentions()):
+        self.layers = []            # (index in diffusers' attn_processors order, module name, Attention)
+        index = attn_processor_index(unet)
+        for name, m in unet.attentions():
             if m.is_cross:
-                self.layers.append((idx, name, m))
+                self.layers.append((index[name], name, m))
+        self.layers.sort(key=lambda t: t[0])
 
     def _install(self, m: Attention, wk: torch.Tensor, wv: torch.Tensor) -> None:
         dev, dt = self.unet.device, self.unet.dtype
+        want = (m.inner_dim, m.to_k.in_features)
+        if tuple(wk.shape) != want or tuple(wv.shape) != want:
+            raise ValueError(f"ip-adapter weights {tuple(wk.shape)} / {tuple(wv.shape)} do not fit this attention layer "
+                             f"(to_k_ip / to_v_ip must be {want}): wrong layer order or wrong checkpoint")
         m.ip_kv_weight = torch.cat([wk, wv], dim=0).to(device=dev, dtype=dt).contiguous()      # [2C, Cx]
         m.ip_scale, m.ip_tokens = self.scale, self.num_tokens
         m._ip_cache = None
@@ -39,6 +59,14 @@ class IPAdapter:
             sd = sd["ip_adapter"]
         for idx, name, m in self.layers:
             self._install(m, sd[f"{idx}.to_k_ip.weight"], sd[f"{idx}.to_v_ip.weight"])
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """The ``ip_adapter`` half of an InstantID ``ip-adapter.bin`` for the installed weights (tests, export)."""
+        out = {}
+        for idx, name, m in self.layers:
+            c = m.inner_dim
+            out[f"{idx}.to_k_ip.weight"], out[f"{idx}.to_v_ip.weight"] = m.ip_kv_weight[:c].clone(), m.ip_kv_weight[c:].clone()
+        return out
 
     def load_named(self, weights: Dict[str, tuple]) -> None:
         """weights[attn2 module name] = (to_k_ip, to_v_ip)."""

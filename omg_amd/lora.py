@@ -20,19 +20,30 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib as L
+from .attention import Attention
 from .modules import GEGLU, Linear
 
 
 class LoraAdapter:
-    """One named adapter: ``weights[module_path] = (A [r, in], B [out, r])`` and its ``alpha``."""
+    """One named adapter: ``weights[module_path] = (A [r, in], B [out, r])`` and its ``alpha``.
 
-    def __init__(self, name: str, weights: Dict[str, Tuple[torch.Tensor, torch.Tensor]], alpha: Optional[float] = None):
+    Layers may have different ranks (PEFT ``rank_pattern``, common in kohya files): ``rank`` is the largest one — the width a
+    layer occupies in the slot stacks, smaller layers are zero-padded — and the PEFT factor ``alpha / r`` uses each layer's own
+    ``r``.  ``alpha=None`` means "alpha equals the rank of every layer" (factor 1), PEFT's and diffusers' default and what the
+    file loaders produce after folding a per-layer ``alpha`` into B.  ``text_encoder`` optionally carries the text-encoder
+    half of the file: ``{1 | 2: {module_path: (A, B)}}`` with factors already folded into B (omg_amd/loaders.py)."""
+
+    def __init__(self, name: str, weights: Dict[str, Tuple[torch.Tensor, torch.Tensor]], alpha: Optional[float] = None,
+                 text_encoder: Optional[Dict[int, Dict[str, Tuple[torch.Tensor, torch.Tensor]]]] = None):
         self.name, self.weights = name, weights
-        ranks = {a.shape[0] for a, _ in weights.values()}
-        if len(ranks) != 1:
-            raise ValueError("per-layer ranks differ inside one adapter; not supported")
-        self.rank = ranks.pop()
+        self.rank = max(a.shape[0] for a, _ in weights.values()) if weights else 0
+        self._alpha_given = alpha is not None
         self.alpha = float(alpha) if alpha is not None else float(self.rank)
+        self.text_encoder = text_encoder or {}
+
+    def scaling(self, key: str) -> float:
+        """PEFT's ``lora_alpha / r`` of one layer."""
+        return self.alpha / self.weights[key][0].shape[0] if self._alpha_given else 1.0
 
 
 def lora_target_names(unet) -> List[str]:
@@ -63,6 +74,7 @@ class LoraBank:
         self.slots: List[Tuple[Tuple[str, float], ...]] = []
         self.scale = 1.0
         self.mode = "merged"
+        self.version = 0             # advances with every build(): engines keyed on it never reuse stale slot stacks
 
     def slot_of(self, combo: Sequence[Tuple[str, float]]) -> int:
         return self.slots.index(tuple((n, float(w)) for n, w in combo))
@@ -101,21 +113,37 @@ class LoraBank:
                         r0 += ad.rank
                         continue
                     a, b = ad.weights[key]
-                    down[s, r0:r0 + ad.rank] = a.to(dev).float()
-                    up[s, :, r0:r0 + ad.rank] = b.to(dev).float() * (scale * w * ad.alpha / ad.rank)
+                    r = a.shape[0]                                   # <= ad.rank; the rest of the adapter's band stays zero
+                    down[s, r0:r0 + r] = a.to(dev).float()
+                    up[s, :, r0:r0 + r] = b.to(dev).float() * (scale * w * ad.scaling(key))
                     r0 += ad.rank
             lin.lora_down = down.to(dt).contiguous()
             lin.lora_up = up.to(dt).contiguous()
             if mode == "merged":
                 base = lin.weight.data.float()
                 lin.w_slots = torch.stack([base] + [base + up[s_] @ down[s_] for s_ in range(len(self.slots))]).to(dt).contiguous()
+        if mode == "merged":
+            # the fused q|k|v (k|v) GEMM takes one weight stack per slot: an attention whose adapter targets only some of
+            # its projections (custom PEFT target_modules) gets the base weight repeated for the others
+            for m in self.unet.modules():
+                if isinstance(m, Attention):
+                    projs = (m.to_q, m.to_k, m.to_v)
+                    if any(l.w_slots is not None for l in projs):
+                        for l in projs:
+                            if l.w_slots is None:
+                                l.w_slots = l.weight.data.unsqueeze(0).repeat(1 + len(self.slots), 1, 1).contiguous()
+        self.version += 1
+        self._invalidate_packed()
+
+    def _invalidate_packed(self) -> None:
+        """Only the modules whose packed images contain LoRA material (fused q|k|v stacks, GEGLU row-interleaved stacks):
+        conv weights are untouched by a slot change and keep their packed form (and their pointers)."""
         for m in self.unet.modules():
-            if m is not self.unet and hasattr(m, "invalidate_packed") and not isinstance(m, Linear):
+            if isinstance(m, (GEGLU, Attention)):
                 m.invalidate_packed()
 
     def clear(self) -> None:
         for m in self.unet.modules():
             if isinstance(m, Linear):
                 m.lora_down = m.lora_up = m.w_slots = None
-            if m is not self.unet and hasattr(m, "invalidate_packed") and not isinstance(m, Linear):
-                m.invalidate_packed()
+        self._invalidate_packed()

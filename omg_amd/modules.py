@@ -31,20 +31,37 @@ class LoraState:
         self.merged = merged
 
 
+# Captured hipGraphs hold raw device pointers of the packed weight images and of the cached cross-attention K / V^T tensors.
+# Every event that frees or re-allocates one of them (LoRA bank rebuild, ``load_state_dict``, ``.to()``, a cache eviction)
+# advances this counter; the step engine compares it before each replay and drops its graphs when it moved
+# (omg_amd/pipeline.py).
+_POINTER_EPOCH = [0]
+
+
+def pointer_epoch() -> int:
+    return _POINTER_EPOCH[0]
+
+
+def bump_pointer_epoch() -> None:
+    _POINTER_EPOCH[0] += 1
+
+
 class _Packed(nn.Module):
     def __init__(self):
         super().__init__()
         self._packed = {}
 
     def invalidate_packed(self):
+        if self._packed:
+            bump_pointer_epoch()
         self._packed = {}
 
     def _load_from_state_dict(self, *a, **k):
-        self._packed = {}
+        self.invalidate_packed()
         return super()._load_from_state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
-        self._packed = {}
+        self.invalidate_packed()
         return super()._apply(fn, *a, **k)
 
 

@@ -31,7 +31,7 @@ from . import _lib as L
 from . import ops
 from .attention import Attention, RegionControlNet_AttnProcessor
 from .lora import LoraBank
-from .modules import LoraState
+from .modules import LoraState, pointer_epoch
 from .schedulers import DDIMScheduler
 
 FUSION_START = 15   # `if i > 15 and stage == 2` (lora_pipeline.py:568) — absolute, not relative
@@ -186,12 +186,17 @@ class LoraMultiConceptPipeline:
             if self.encode_prompt is None:
                 raise L.OmgHipError("no text encoders attached: pass prompt_embeds=/pooled_prompt_embeds= (and region_prompt_embeds=) or "
                                     "construct the pipeline with encode_prompt=omg_amd.text_encoder.make_encode_prompt(...)")
+            # global prompt on the main pipe (its text encoders carry the style LoRA when one is loaded, inference_lora.py:162-164),
+            # region prompts on the concept pipe with the concept's adapters active (lora_pipeline.py:315-347); both with
+            # lora_scale = cross_attention_kwargs["scale"]
+            te_scale = (cross_attention_kwargs or {}).get("scale", None)
             global_prompt, regions = prompt[0], prompt[1]
             prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = self.encode_prompt(
-                global_prompt, negative_prompt, None)
+                global_prompt, negative_prompt, [("style", 1.0)] if styleL else None, te_scale)
             region_prompt_embeds = []
             for lora_param, (rp, rn) in zip(lora_list, [(r[0], r[1]) for r in regions]):
-                pe, ne, pp, npp = self.encode_prompt(rp, rn, lora_param)
+                combo = [(lora_param, 0.7), ("style", 0.5)] if styleL else [(lora_param, 1.0)]
+                pe, ne, pp, npp = self.encode_prompt(rp, rn, combo, te_scale)
                 region_prompt_embeds.append((ne, pe, npp, pp))
         req = dict(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
                    pooled_prompt_embeds=pooled_prompt_embeds, negative_pooled_prompt_embeds=negative_pooled_prompt_embeds,
@@ -293,23 +298,34 @@ class LoraMultiConceptPipeline:
         emb_main = self._all_step_embeddings(ts, torch.cat(text_l, dim=0),
                                              self._add_time_ids(original_size, crops_coords_top_left, target_size, nm, dev))
         slots: List[int] = []
+        if fuse_possible and concept_models is None:
+            raise ValueError("stage 2 needs concept_models")
+        # ---- LoRA slots.  Concept passes: set_adapters(lora) or set_adapters([lora, "style"], [0.7, 0.5]) (lora_pipeline.py:588-591).
+        # MAIN pass: inference_lora.py:162-164 loads the style LoRA into the main pipe as well, and the main UNet is called with
+        # cross_attention_kwargs={"scale": 0.8} (:546-566), so with styleL every main sample runs with adapter "style" at PEFT
+        # weight 1.0 x scale — one more slot of the same bank, selected for the main rows in plain AND fused steps.
+        scale = (cross_attention_kwargs or {}).get("scale", 1.0)
+        bank = concept_models.bank if concept_models is not None else None
+        combos = []
         if fuse_possible:
-            if concept_models is None:
-                raise ValueError("stage 2 needs concept_models")
-            scale = (cross_attention_kwargs or {}).get("scale", 1.0)
             combos = [((lora_list[c], 0.7), ("style", 0.5)) if styleL else ((lora_list[c], 1.0),) for c in active]
-            if concept_models.bank is not None:
-                bank = concept_models.bank
-                if [tuple(c) for c in combos] != list(bank.slots) or bank.scale != scale or bank.mode != lora_mode:
-                    bank.build(combos, scale=scale, mode=lora_mode)
-                slots = [s for _ in range(n) for s in range(Ka) for _ in range(2)]
-            else:
-                slots = [-1] * ncn
+        main_slot = -1
+        if styleL:
+            if bank is None or "style" not in bank.adapters:
+                raise ValueError("styleL=True needs concept_models with a LoraBank holding the adapter named 'style'")
+            main_slot = len(combos)
+            combos = combos + [(("style", 1.0),)]
+        if bank is not None and combos:
+            if [tuple(c) for c in combos] != list(bank.slots) or bank.scale != scale or bank.mode != lora_mode:
+                bank.build(combos, scale=scale, mode=lora_mode)
+        if fuse_possible:
+            slots = [s for _ in range(n) for s in range(Ka) for _ in range(2)] if bank is not None else [-1] * ncn
             c_ehs = torch.cat(cehs_l, dim=0).contiguous()                                           # (2Ka*n, 77, Cx)
             emb_conc = self._all_step_embeddings(ts, torch.cat(ctext_l, dim=0),
                                                  self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev))
-        batched = fuse_possible and (concept_models.bank is None or concept_models.bank.mode == "merged")
-        if use_graph and fuse_possible and not batched:
+        merged = bank is not None and bank.mode == "merged"
+        batched = fuse_possible and (bank is None or merged)
+        if use_graph and not (bank is None or merged) and (fuse_possible or main_slot >= 0):
             raise L.OmgHipError("use_graph needs lora_mode='merged' (segment-mode K/V projections are not pointer-stable)")
         use_cn = controlnet is not None
         use_idn = identitynet is not None and fuse_possible
@@ -354,6 +370,9 @@ class LoraMultiConceptPipeline:
             if len(self._engines) >= 4:
                 self._engines.pop(next(iter(self._engines)))
             self._engines[key] = eng
+            # the key holds id()s: keep the objects alive so that an id cannot be recycled for a different object
+            eng.refs = (controller, controlnet, identitynet, concept_models)
+            eng.epoch = pointer_epoch()
         # ---- load this call's inputs into the static buffers (device-to-device copies; graphs keep their pointers)
         lat = eng.lat
         lat.copy_(torch.cat(lats, dim=0))
@@ -381,7 +400,11 @@ class LoraMultiConceptPipeline:
             eng.ehs_all[nm:].copy_(c_ehs)
             eng.emb_all[:, :nm].copy_(emb_main)
             eng.emb_all[:, nm:].copy_(emb_conc)
-            state_all = concept_models.lora_state([0] * nm + [s + 1 for s in slots], merged=True) if concept_models.bank is not None else None
+            state_all = concept_models.lora_state([main_slot + 1] * nm + [s + 1 for s in slots], merged=True) if bank is not None else None
+        # main-only forwards (plain steps; the main half of un-batched fused steps): base weights, or the style slot
+        state_main = None
+        if main_slot >= 0:
+            state_main = concept_models.lora_state([main_slot + 1] * nm, merged=True) if merged else concept_models.lora_state([main_slot] * nm, merged=False)
         tids_m = self._add_time_ids(original_size, crops_coords_top_left, target_size, nm, dev)
         if use_cn:
             eng.cn_image.copy_(controlnet_image.to(device=dev, dtype=torch.float32))
@@ -396,7 +419,7 @@ class LoraMultiConceptPipeline:
         if use_graph:
             # cached cross-attention K/V (and ControlNet conditioning features) must be refreshed eagerly:
             # replayed graphs read the stored tensors
-            self.unet.refresh_cross_kv(eng.ehs, None)
+            self.unet.refresh_cross_kv(eng.ehs, state_main)
             if batched:
                 self.unet.refresh_cross_kv(eng.ehs_all, state_all)
             if use_cn:
@@ -434,7 +457,7 @@ class LoraMultiConceptPipeline:
                 if residuals:
                     kw["omg_residuals"] = residuals
                 ops.gather_step(eng.emb_all, step_idx, eng.emb_cur_all)
-                self.unet.set_lora_state(state_all if concept_models.bank is not None else None)
+                self.unet.set_lora_state(state_all)
                 try:
                     self.unet(xin, None, encoder_hidden_states=eng.ehs_all, cross_attention_kwargs=kw, emb=eng.emb_cur_all, out=nout)
                 finally:
@@ -443,7 +466,11 @@ class LoraMultiConceptPipeline:
                 if residuals:
                     kw["omg_residuals"] = residuals
                 ops.gather_step(eng.emb_main, step_idx, eng.emb_cur_main)
-                self.unet(xin[:nm], None, encoder_hidden_states=eng.ehs, cross_attention_kwargs=kw, emb=eng.emb_cur_main, out=nout[:nm])
+                self.unet.set_lora_state(state_main)
+                try:
+                    self.unet(xin[:nm], None, encoder_hidden_states=eng.ehs, cross_attention_kwargs=kw, emb=eng.emb_cur_main, out=nout[:nm])
+                finally:
+                    self.unet.set_lora_state(None)
                 if fused:
                     fill_region_inputs()
                     ops.gather_step(eng.emb_conc, step_idx, eng.emb_cur_conc)
@@ -463,6 +490,10 @@ class LoraMultiConceptPipeline:
             if not use_graph:
                 step_body(fused)
                 return
+            if eng.epoch != pointer_epoch():          # a weight image or cached K/V the graphs point at was freed or re-allocated
+                eng.graphs.clear()
+                eng.warmed.clear()
+                eng.epoch = pointer_epoch()
             win = controller._self_window() if controller is not None and hasattr(controller, "_self_window") else None
             regime = (fused, win)
             g = eng.graphs.get(regime)

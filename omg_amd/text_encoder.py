@@ -95,23 +95,51 @@ class ClipTextEncoder(nn.Module):
         self._packed = None
         return super().load_state_dict(*a, **k)
 
+    def set_lora(self, combo=None) -> None:
+        """Activate text-encoder LoRA deltas for the following forwards: ``combo`` = [(weights, multiplier), ...] with
+        ``weights[module path] = (A [r, in], B [out, r])`` (``LoraAdapter.text_encoder[n]``) and multiplier =
+        ``lora_scale * adapter_weight`` — PEFT's ``set_adapters`` + ``scale_lora_layers(text_encoder, lora_scale)`` as
+        ``encode_prompt`` runs them (lora_pipeline.py:336-347).  The deltas are merged into the packed weight images in fp32
+        (one rounding); ``None`` restores the base weights."""
+        combo = [(w, float(m)) for w, m in (combo or []) if w]
+        sig = tuple((id(w), m) for w, m in combo)
+        if sig != getattr(self, "_lora_sig", ()):
+            self._lora, self._lora_sig, self._packed = combo, sig, None
+
+    def _w(self, li: int, sub: str, lin: Linear) -> torch.Tensor:
+        """Weight of ``text_model.encoder.layers.<li>.<sub>`` with the active LoRA deltas merged in."""
+        w = lin.weight.data
+        key = f"text_model.encoder.layers.{li}.{sub}"
+        hits = [(wd[key], m) for wd, m in getattr(self, "_lora", None) or [] if key in wd]
+        if not hits:
+            return w
+        acc = w.float()
+        for (a, b), m in hits:
+            acc = acc + m * (b.to(device=w.device, dtype=torch.float32) @ a.to(device=w.device, dtype=torch.float32))
+        return acc.to(w.dtype)
+
     def _pack(self):
         """Derived weight images: q|k|v rows concatenated; quick_gelu's 1/1.702 folded into fc2; gelu's fc1 as a GEGLU GEMM with
-        a constant-one value half; the causal mask."""
+        a constant-one value half; the causal mask; active LoRA deltas merged."""
         cfg, dev, dt = self.config, self.device, self._dtype
         layers = []
-        for lyr in self.text_model.encoder.layers:
+        for li, lyr in enumerate(self.text_model.encoder.layers):
             a = lyr.self_attn
-            pk = {"wqkv": torch.cat([a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data]).contiguous(),
-                  "bqkv": torch.cat([a.q_proj.bias.data, a.k_proj.bias.data, a.v_proj.bias.data]).contiguous()}
+            pk = {"wqkv": torch.cat([self._w(li, "self_attn.q_proj", a.q_proj), self._w(li, "self_attn.k_proj", a.k_proj),
+                                     self._w(li, "self_attn.v_proj", a.v_proj)]).contiguous(),
+                  "bqkv": torch.cat([a.q_proj.bias.data, a.k_proj.bias.data, a.v_proj.bias.data]).contiguous(),
+                  "wo": self._w(li, "self_attn.out_proj", a.out_proj)}
+            w1, w2 = self._w(li, "mlp.fc1", lyr.mlp.fc1), self._w(li, "mlp.fc2", lyr.mlp.fc2)
             if cfg.hidden_act == "quick_gelu":
-                pk["w2"] = (lyr.mlp.fc2.weight.data.float() / 1.702).to(dt).contiguous()
+                pk["w1"] = w1
+                pk["w2"] = (w2.float() / 1.702).to(dt).contiguous()
             else:
                 f = cfg.intermediate_size
                 perm = ops.geglu_row_perm(2 * f).to(dev)
-                w1 = torch.cat([torch.zeros_like(lyr.mlp.fc1.weight.data), lyr.mlp.fc1.weight.data])
+                w1g = torch.cat([torch.zeros_like(w1), w1])
                 b1 = torch.cat([torch.ones_like(lyr.mlp.fc1.bias.data), lyr.mlp.fc1.bias.data])
-                pk["w1g"], pk["b1g"] = w1[perm].contiguous(), b1[perm].contiguous()
+                pk["w1g"], pk["b1g"] = w1g[perm].contiguous(), b1[perm].contiguous()
+                pk["w2"] = w2
             layers.append(pk)
         T = self.TP
         mask = torch.zeros(T, T, dtype=dt, device=dev)
@@ -153,14 +181,13 @@ class ClipTextEncoder(nn.Module):
                     ops.add_(scores, pk["mask"])
                     ops.softmax_rows_(scores, 1.0)
                     ops.gemm(scores, vt[b, hh, :, :T], out=attn[b * T:(b + 1) * T, hh * 64:(hh + 1) * 64])
-            x = lyr.self_attn.out_proj(attn, residual=x)
+            x = ops.gemm(attn, w["wo"], bias=lyr.self_attn.out_proj.bias.data, residual=x)
             h = lyr.layer_norm2(x)
             if cfg.hidden_act == "quick_gelu":
-                f = ops.silu(ops.gemm(h, lyr.mlp.fc1.weight.data, bias=lyr.mlp.fc1.bias.data, out_scale=1.702))
-                x = ops.gemm(f, w["w2"], bias=lyr.mlp.fc2.bias.data, residual=x)
+                f = ops.silu(ops.gemm(h, w["w1"], bias=lyr.mlp.fc1.bias.data, out_scale=1.702))
             else:
                 f = ops.gemm(h, w["w1g"], bias=w["b1g"], act=L.ACT_GEGLU)
-                x = lyr.mlp.fc2(f, residual=x)
+            x = ops.gemm(f, w["w2"], bias=lyr.mlp.fc2.bias.data, residual=x)
         last = self.text_model.final_layer_norm(x).view(B, T, d)
         eos = (ids == cfg.eos_token_id).int().argmax(dim=-1)
         pooled = last[torch.arange(B, device=ids.device), eos].contiguous()
@@ -177,29 +204,49 @@ def encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, ids_l: torch.T
     return torch.cat([hl, hg], dim=-1), pooled
 
 
-def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_l, tokenize_g=None):
+def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_l, tokenize_g=None, adapters=None):
     """The ``encode_prompt=`` callable of :class:`omg_amd.pipeline.LoraMultiConceptPipeline`:
-    ``fn(prompt, negative_prompt, lora_param) -> (prompt_embeds, negative_prompt_embeds, pooled, negative_pooled)`` as diffusers'
-    ``StableDiffusionXLPipeline.encode_prompt`` returns them (lora_pipeline.py:315-347).  ``tokenize_*`` map a list of strings to
-    (B, 77) int64 ids (the reference's ``pipe.tokenizer`` / ``pipe.tokenizer_2`` with ``padding="max_length"``).  A ``None``
-    negative prompt gives zero embeddings (SDXL-base ships ``force_zeros_for_empty_prompt=True``).  ``lora_param`` is accepted
-    and ignored: only the UNet half of a LoRA file is applied on this path (omg_amd/loaders.py)."""
+    ``fn(prompt, negative_prompt, lora_param, lora_scale) -> (prompt_embeds, negative_prompt_embeds, pooled, negative_pooled)`` as
+    diffusers' ``StableDiffusionXLPipeline.encode_prompt`` returns them (lora_pipeline.py:315-347).  ``tokenize_*`` map a list of
+    strings to (B, 77) int64 ids (the reference's ``pipe.tokenizer`` / ``pipe.tokenizer_2`` with ``padding="max_length"``).  A
+    ``None`` negative prompt gives zero embeddings (SDXL-base ships ``force_zeros_for_empty_prompt=True``).
+
+    ``lora_param``: the adapters active on the text encoders while this prompt is encoded — ``None``, an adapter name, or
+    [(name, weight), ...] (the reference calls ``concept_models.set_adapters(lora)`` / ``set_adapters([lora, "style"], [0.7, 0.5])``
+    right before ``concept_models.encode_prompt(..., lora_scale=0.8)``, lora_pipeline.py:336-347).  ``adapters`` maps names to
+    :class:`omg_amd.lora.LoraAdapter` objects whose ``text_encoder[1]`` / ``[2]`` hold the CLIP-L / OpenCLIP-bigG halves of the LoRA
+    file (omg_amd/loaders.py); an adapter without text-encoder entries changes nothing."""
     tokenize_g = tokenize_g or tokenize_l
+    adapters = adapters if adapters is not None else {}
 
     def _list(p, n):
         out = [p] if isinstance(p, str) else list(p)
         return out * n if len(out) == 1 and n > 1 else out
 
-    def fn(prompt, negative_prompt=None, lora_param=None):
-        prompts = _list(prompt, 1)
-        dev = enc_l.device
-        pe, pp = encode_prompt(enc_l, enc_g, tokenize_l(prompts).to(dev), tokenize_g(prompts).to(dev))
-        if negative_prompt is None:
-            return pe, torch.zeros_like(pe), pp, torch.zeros_like(pp)
-        negs = _list(negative_prompt, len(prompts))
-        if len(negs) != len(prompts):
-            raise ValueError("negative_prompt must be one string or one per prompt")
-        ne, npp = encode_prompt(enc_l, enc_g, tokenize_l(negs).to(dev), tokenize_g(negs).to(dev))
-        return pe, ne, pp, npp
+    def fn(prompt, negative_prompt=None, lora_param=None, lora_scale=None):
+        combo = [] if lora_param is None else [(lora_param, 1.0)] if isinstance(lora_param, str) else list(lora_param)
+        ls = 1.0 if lora_scale is None else float(lora_scale)
+        for n_te, enc in ((1, enc_l), (2, enc_g)):
+            act = []
+            for name, w in combo:
+                if name not in adapters:
+                    raise KeyError(f"text-encoder LoRA: adapter {name!r} was not given to make_encode_prompt(adapters=...)")
+                act.append((adapters[name].text_encoder.get(n_te), ls * float(w)))
+            enc.set_lora(act)
+        try:
+            prompts = _list(prompt, 1)
+            dev = enc_l.device
+            pe, pp = encode_prompt(enc_l, enc_g, tokenize_l(prompts).to(dev), tokenize_g(prompts).to(dev))
+            if negative_prompt is None:
+                return pe, torch.zeros_like(pe), pp, torch.zeros_like(pp)
+            negs = _list(negative_prompt, len(prompts))
+            if len(negs) != len(prompts):
+                raise ValueError("negative_prompt must be one string or one per prompt")
+            ne, npp = encode_prompt(enc_l, enc_g, tokenize_l(negs).to(dev), tokenize_g(negs).to(dev))
+            return pe, ne, pp, npp
+        finally:
+            enc_l.set_lora(None)
+            enc_g.set_lora(None)
 
+    fn.adapters = adapters
     return fn

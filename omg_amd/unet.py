@@ -269,14 +269,17 @@ class UNet2DConditionModel(nn.Module):
         self.time_embedding = TimestepEmbedding(c0, ted, dtype, device)
         self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, ted, dtype, device)
         nb = len(cfg.block_out_channels)
+        # Registration order follows diffusers' UNet2DConditionModel.__init__, which creates BOTH block lists before the mid
+        # block: named_modules() / ``attn_processors`` therefore enumerate down_blocks, up_blocks, mid_block — the order the
+        # InstantID ``ip_adapter`` checkpoint is indexed by (instantid_single_pieline.py:186-213).
         self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()
         cout = c0
         for i, typ in enumerate(cfg.down_block_types):
             cin, cout = cout, cfg.block_out_channels[i]
             cls = CrossAttnDownBlock2D if typ == "CrossAttnDownBlock2D" else DownBlock2D
             self.down_blocks.append(cls(cfg, i, cin, cout, typ == "CrossAttnDownBlock2D", i != nb - 1, dtype, device))
         self.mid_block = UNetMidBlock2DCrossAttn(cfg, dtype, device)
-        self.up_blocks = nn.ModuleList()
         rev = list(reversed(cfg.block_out_channels))
         rev_heads = list(reversed(cfg.attention_head_dim))
         rev_layers = list(reversed(cfg.transformer_layers_per_block))

@@ -188,3 +188,110 @@ def test_generate_many_equals_single_requests(dev):
         assert (pctl.cur_step, pctl.cur_att_layer) == (S, 0)
         for j in range(3):
             assert torch.equal(many[j], singles[j]), f"request {j} (graph={use_graph}): max diff {(many[j] - singles[j]).abs().max().item()}"
+
+
+@pytest.mark.parametrize("lora_mode", ["merged", "segment"])
+def test_style_lora_runs_on_the_main_pass_too(dev, lora_mode):
+    """styleL (inference_lora.py:162-164, :253-254): the style LoRA is loaded into the MAIN pipe as well, so every main forward
+    carries adapter 'style' at PEFT weight 1.0 x scale 0.8, while concept c runs set_adapters([c, 'style'], [0.7, 0.5])
+    (lora_pipeline.py:588-591).  The style adapter here targets no to_q (partial coverage of an attention's projections)."""
+    dtype = torch.float16
+    cfg, ocfg, sd, unet = setup(dev, dtype)
+    L = cfg.sample_size
+    S, gs, fstart = 8, 7.5, 3
+    H = W = L * 8
+    neg_e, neg_p = embeds(cfg, 1, 1, dtype)
+    pos_e, pos_p = embeds(cfg, 1, 2, dtype)
+    pe, ne, pp, npp = pos_e.repeat(2, 1, 1), neg_e.repeat(2, 1, 1), pos_p.repeat(2, 1), neg_p.repeat(2, 1)
+    regions = []
+    for c in range(2):
+        re_, rp_ = embeds(cfg, 2, 10 + c, dtype)
+        regions.append((re_[0:1], re_[1:2], rp_[0:1], rp_[1:2]))
+    m1 = torch.zeros(H, W); m1[H // 4:, W // 16: W // 2] = 1
+    m2 = torch.zeros(H, W); m2[H // 4:, W // 2 - 16: W - 8] = 1
+    masks = [m1, m2]
+    lat0 = torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(14))
+    tid = torch.tensor([[H, W, 0, 0, H, W]], dtype=torch.float32)
+    names = ou.lora_target_names(ocfg)
+    style_names = [k for k in names if not k.endswith(".to_q")]
+    ow, ofn = {}, {}
+    for nm_, seed, tn in (("c0", 100, names), ("c1", 101, names), ("style", 102, style_names)):
+        ow[nm_], ofn[nm_] = ou.make_lora(ocfg, tn, rank=8, seed=seed, scale=0.8, dtype=dtype)
+    bank = LoraBank(unet, [LoraAdapter(k, {n: (a.to(dev), b.to(dev)) for n, (a, b) in w.items()}) for k, w in ow.items()])
+    concept = ConceptModels(unet, bank)
+    args = ([P, P], S, {"default_": 1.0}, 0.4, L // 4, L // 4)
+    pctl = pc.AttentionReplace(*args, device=dev)
+    revise_regionally_controlnet_forward(unet, pctl)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
+    osch = osched.make("ddim", S)
+
+    def oracle_run(stage, style):
+        octl = oc.AttentionReplaceOracle(*args)
+        octl.num_att_layers = pctl.num_att_layers
+        attn = oc.reference_attn_fn(octl)
+        ctx4 = torch.cat([ne, pe]); te4 = torch.cat([npp, pp])
+        main_lora = ofn["style"] if style else None
+        def main(x, i):
+            return ou.unet_forward(sd, ocfg, x, float(osch.timesteps[i]), ctx4, te4, tid.repeat(4, 1), attn_fn=attn, lora=main_lora)
+        def conc(c):
+            ctx2 = torch.cat([regions[c][0], regions[c][1]]); te2 = torch.cat([regions[c][2], regions[c][3]])
+            fn = (lambda key, x: 0.7 * ofn[f"c{c}"](key, x) + 0.5 * ofn["style"](key, x)) if style else ofn[f"c{c}"]
+            return lambda x, i: ou.unet_forward(sd, ocfg, x, float(osch.timesteps[i]), ctx2, te2, tid.repeat(2, 1), lora=fn)
+        return opipe.denoise(main, [conc(c) for c in range(2)], osch, lat0 * osch.init_noise_sigma, S, gs, stage, masks=masks, fusion_start=fstart)
+
+    outs = {}
+    for stage in (1, 2):
+        pctl.reset()
+        out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp,
+                   height=H, width=W, num_inference_steps=S, guidance_scale=gs, latents=lat0, cross_attention_kwargs={"scale": 0.8},
+                   controller=pctl, concept_models=concept, stage=stage, region_masks=masks, lora_list=["c0", "c1"], styleL=True,
+                   region_prompt_embeds=regions, fusion_start=fstart, lora_mode=lora_mode).images.float().cpu()
+        ref = oracle_run(stage, True)
+        rms = ref.pow(2).mean().sqrt().item()
+        rel = (out - ref).abs().max().item() / rms
+        plain = oracle_run(stage, False)
+        print(f"styleL {lora_mode} stage {stage}: rel err {rel:.2e}; style moves the oracle by {(ref - plain).abs().max().item() / rms:.2e} rms")
+        assert rel < 2e-2, rel
+        assert (ref - plain).abs().max().item() / rms > 10 * rel, "the style adapter must matter far more than the tolerance"
+        outs[stage] = out
+
+
+def test_stale_graphs_are_dropped_when_the_bank_is_rebuilt(dev):
+    """call A (two masks, graphs captured) -> call B (one mask: the LoRA bank is rebuilt, weight stacks and cached
+    K/V are re-allocated) -> call A again must not replay graphs that point at freed memory: equal to the eager result."""
+    dtype = torch.float16
+    cfg, ocfg, sd, unet = setup(dev, dtype)
+    L = cfg.sample_size
+    S, gs, fstart = 8, 7.5, 2
+    H = W = L * 8
+    names = ou.lora_target_names(ocfg)
+    bank = LoraBank(unet, [LoraAdapter(f"c{c}", {k: (a.to(dev), b.to(dev)) for k, (a, b) in ou.make_lora(ocfg, names, 8, 100 + c, 0.8, dtype)[0].items()}) for c in range(2)])
+    concept = ConceptModels(unet, bank)
+    pctl = pc.AttentionReplace([P, P], S, {"default_": 1.0}, 0.5, L // 4, L // 4, device=dev)
+    revise_regionally_controlnet_forward(unet, pctl)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
+    m1 = torch.zeros(H, W); m1[H // 4:, : W // 2] = 1
+    m2 = torch.zeros(H, W); m2[H // 4:, W // 2 - 16:] = 1
+
+    def run(masks, use_graph, scale=0.8):
+        pe1, pp1 = embeds(cfg, 1, 3, dtype); ne1, np1 = embeds(cfg, 1, 53, dtype)
+        regions = []
+        for c in range(2):
+            re_, rp_ = embeds(cfg, 2, 13 + c, dtype)
+            regions.append((re_[0:1], re_[1:2], rp_[0:1], rp_[1:2]))
+        pctl.reset()
+        return pipe(prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
+                    negative_pooled_prompt_embeds=np1.repeat(2, 1), height=H, width=W, num_inference_steps=S, guidance_scale=gs,
+                    latents=torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(5)), cross_attention_kwargs={"scale": scale},
+                    controller=pctl, concept_models=concept, stage=2, region_masks=masks, lora_list=["c0", "c1"], styleL=False,
+                    region_prompt_embeds=regions, fusion_start=fstart, use_graph=use_graph).images.cpu()
+
+    eager_a, eager_b = run([m1, m2], False), run([m1, None], False)
+    ga1 = run([m1, m2], True)
+    gb = run([m1, None], True)           # rebuilds the bank with ONE slot
+    ga2 = run([m1, m2], True)            # rebuilds it with two: the first call's graphs are stale now
+    ga3 = run([m1, m2], True, scale=0.5) # same engine key shape, different LoRA scale
+    assert torch.equal(ga1, eager_a) and torch.equal(gb, eager_b)
+    assert torch.equal(ga2, eager_a), (ga2 - eager_a).abs().max()
+    assert torch.equal(ga3, run([m1, m2], False, scale=0.5))
+    assert not torch.equal(ga3, eager_a)

@@ -84,3 +84,57 @@ def test_make_encode_prompt_contract(dev):
     assert torch.equal(pe[:1], encode_prompt(enc_l, enc_g, ids, ids)[0])
     pe2, ne2, pp2, npp2 = fn("a man and a woman")
     assert torch.equal(pe2, pe[:1]) and float(ne2.abs().max()) == 0.0 and float(npp2.abs().max()) == 0.0
+
+
+def test_text_encoder_lora_matches_oracle_and_is_scoped_to_the_call(dev):
+    """Region prompts are encoded with the concept LoRA active on the text encoders (lora_pipeline.py:336-347:
+    set_adapters([lora, "style"], [0.7, 0.5]) then encode_prompt(..., lora_scale=0.8)).  Oracle: the fp32 text model on
+    W + sum_a 0.8 * w_a * B_a A_a (PEFT's un-merged sum, equal up to rounding)."""
+    from omg_amd.lora import LoraAdapter
+    from omg_amd.text_encoder import make_encode_prompt
+    dtype = torch.float16
+    ocfg_l, sd_l, enc_l = _pair("quick_gelu", False, dev, dtype, seed=5)
+    ocfg_g, sd_g, enc_g = _pair("gelu", True, dev, dtype, seed=6)
+    g = torch.Generator().manual_seed(9)
+
+    def te_weights(sd, rank):
+        out = {}
+        for k, v in sd.items():
+            if k.endswith(".weight") and any(s in k for s in ("q_proj", "k_proj", "v_proj", "out_proj", "fc1", "fc2")):
+                o, i = v.shape
+                out[k[: -len(".weight")]] = ((torch.randn(rank, i, generator=g) * i ** -0.5).to(dtype).float(),
+                                             (torch.randn(o, rank, generator=g) * 0.3).to(dtype).float())
+        return out
+
+    ads = {"c0": LoraAdapter("c0", {}, text_encoder={1: te_weights(sd_l, 4), 2: te_weights(sd_g, 4)}),
+           "style": LoraAdapter("style", {}, text_encoder={1: te_weights(sd_l, 8)})}       # style file without a second-encoder half
+    ids = {"p": _ids(1, 11), "n": _ids(1, 12)}
+    fn = make_encode_prompt(enc_l, enc_g, lambda ps: torch.cat([ids[p] for p in ps]), adapters=ads)
+
+    def oracle(combo, scale):
+        outs = []
+        for which in ("p", "n"):
+            hs = []
+            for n_te, ocfg, sd in ((1, ocfg_l, sd_l), (2, ocfg_g, sd_g)):
+                sd2 = dict(sd)
+                for name, w in combo:
+                    for mod, (a, b) in ads[name].text_encoder.get(n_te, {}).items():
+                        sd2[mod + ".weight"] = sd2[mod + ".weight"] + scale * w * (b @ a)
+                hidden, last, pooled = ot.text_model(sd2, ocfg, ids[which])
+                hs.append(hidden[-2])
+            outs += [torch.cat(hs, dim=-1), pooled]
+        return outs   # pe, pp, ne, npp
+
+    base = fn("p", "n")
+    combo = [("c0", 0.7), ("style", 0.5)]
+    pe, ne, pp, npp = fn("p", "n", combo, 0.8)
+    rpe, rpp, rne, rnpp = oracle(combo, 0.8)
+    rms = rpe.pow(2).mean().sqrt()
+    for got, ref in ((pe, rpe), (ne, rne), (pp, rpp), (npp, rnpp)):
+        assert (got.float().cpu() - ref).abs().max() / ref.pow(2).mean().sqrt() < 2e-2
+    moved = (rpe - oracle([], 0.8)[0]).abs().max() / rms
+    assert moved > 0.2, moved                                          # the LoRA matters far more than the tolerance
+    again = fn("p", "n")
+    assert all(torch.equal(a, b) for a, b in zip(base, again)), "the adapters must be active for that one call only"
+    one = fn("p", "n", "c0", 0.8)                                       # a bare adapter name = weight 1.0
+    assert (one[0].float().cpu() - oracle([("c0", 1.0)], 0.8)[0]).abs().max() / rms < 2e-2
