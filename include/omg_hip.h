@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMG_ABI_VERSION 3
+#define OMG_ABI_VERSION 4
 
 enum { OMG_F16 = 0, OMG_BF16 = 1, OMG_F32 = 2 /* only where a signature says so */ };
 
@@ -87,6 +87,44 @@ typedef struct {
 } omg_gemm_args;
 
 int omg_gemm(const omg_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------
+ * omg_quant_mx8 / omg_gemm_mx8 — the same Linear layers with OCP MX fp8
+ * operands (BASELINE.json north_star "MFMA bf16/fp8", configs[4]): elements
+ * e4m3, one E8M0 scale (2^(s-127)) per 32 consecutive K elements, contraction
+ * on v_mfma_scale_f32_32x32x64_f8f6f4 (the 5 PFLOP/s path of gfx950), fp32
+ * accumulation, fp16 / bf16 output with the epilogues of omg_gemm.
+ *
+ * Scale layout (both operands): uint32 S[K/128][ld]; S[t][r] packs the four
+ * scale bytes of row r for K blocks 4t .. 4t+3 (byte b = block 4t + b).
+ *
+ * omg_quant_mx8: X[M,K] (fp16 / bf16, row stride ldx elements) -> Q[M,K]
+ * bytes (row stride ldq) + S.  Scale = smallest power of two with
+ * amax / scale <= 448 (no element saturates).  K % 128 == 0, s_ld >= M.
+ * Weights are quantised once with the same call (rows = output features).
+ * ---------------------------------------------------------------------- */
+int omg_quant_mx8(int32_t dtype, const void* x, int64_t ldx, int32_t M, int32_t K,
+                  void* q, int64_t ldq, void* scales, int32_t s_ld, void* stream);
+
+typedef struct {
+  int32_t dtype;              /* type of C, bias, residual: OMG_F16 | OMG_BF16        */
+  int32_t M, N, K;            /* K % 128 == 0, N % 8 == 0                             */
+  const void* A; int64_t lda; /* e4m3 bytes [M, K], lda % 16 == 0                     */
+  const void* a_scale; int32_t sa_ld;   /* uint32 [K/128][sa_ld], sa_ld >= M          */
+  const void* W; int64_t ldw; /* e4m3 bytes [N, K] (per adapter), ldw % 16 == 0       */
+  const void* w_scale; int32_t sw_ld;   /* uint32 [K/128][sw_ld]                      */
+  int32_t groups, rows_per_group;       /* as omg_gemm                                */
+  const int32_t* group_adapter;         /* [groups] weight slot per sample or NULL    */
+  int64_t w_adapter_stride;   /* bytes (= elements) between weight slots; 0 = shared  */
+  int64_t sw_adapter_stride;  /* scale columns between weight slots (normally N)      */
+  const void* bias;           /* [N] or NULL                                          */
+  const void* residual; int64_t ldr;
+  int32_t act;                /* OMG_ACT_NONE | OMG_ACT_SILU | OMG_ACT_GEGLU          */
+  float out_scale;
+  void* C; int64_t ldc;
+} omg_gemm_mx8_args;
+
+int omg_gemm_mx8(const omg_gemm_mx8_args* a, void* stream);
 
 /* ------------------------------------------------------------------------
  * omg_conv2d — NHWC implicit-GEMM convolution (3x3 pad 1, or 1x1), stride 1|2,

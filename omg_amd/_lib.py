@@ -34,6 +34,19 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmMx8Args(C.Structure):
+    _fields_ = [
+        ("dtype", c_i32), ("M", c_i32), ("N", c_i32), ("K", c_i32),
+        ("A", c_vp), ("lda", c_i64), ("a_scale", c_vp), ("sa_ld", c_i32),
+        ("W", c_vp), ("ldw", c_i64), ("w_scale", c_vp), ("sw_ld", c_i32),
+        ("groups", c_i32), ("rows_per_group", c_i32), ("group_adapter", c_vp),
+        ("w_adapter_stride", c_i64), ("sw_adapter_stride", c_i64),
+        ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
+        ("act", c_i32), ("out_scale", c_f32),
+        ("C", c_vp), ("ldc", c_i64),
+    ]
+
+
 class Conv2dArgs(C.Structure):
     _fields_ = [
         ("dtype", c_i32), ("B", c_i32), ("Hin", c_i32), ("Win", c_i32),
@@ -71,6 +84,8 @@ SYMBOLS = {
     "omg_abi_version": (c_i32, []),
     "omg_last_error": (C.c_char_p, []),
     "omg_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
+    "omg_quant_mx8": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp]),
+    "omg_gemm_mx8": (c_i32, [C.POINTER(GemmMx8Args), c_vp]),
     "omg_conv2d": (c_i32, [C.POINTER(Conv2dArgs), c_vp]),
     "omg_attn_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
     "omg_transpose_v": (c_i32, [c_i32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -93,6 +108,7 @@ SYMBOLS = {
     "omg_debug_set_glds": (None, [c_i32]),
     "omg_debug_set_gemm_variant": (None, [c_i32]),
     "omg_debug_choose_variant": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    "omg_debug_set_mx8_split": (None, [c_i32]),
 }
 
 _lib = None
@@ -123,7 +139,7 @@ def lib() -> C.CDLL:
         fn = getattr(l, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if l.omg_abi_version() != 3:
+    if l.omg_abi_version() != 4:
         raise OmgHipError("libomg_hip.so ABI version mismatch; rebuild")
     v = os.environ.get("OMG_GEMM_VARIANT")      # debugging/benchmarking aid: force one GEMM tile configuration
     if v:

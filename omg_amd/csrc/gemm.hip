@@ -21,6 +21,7 @@
 // row-coalesced stores; v6-v8 accumulate the transposed tile and store 16 bytes per lane straight from registers
 // (epilogue_direct).  Measurements and the rejected alternatives: DESIGN.md §5.
 #include "common.h"
+#include "gemm_epilogue.h"
 
 __device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
 
@@ -35,30 +36,6 @@ constexpr int LDS_BYTES_MAIN = 4 * TILE_BYTES;   // A[2] + B[2]
 constexpr int LDS_BYTES_EPI = 4 * 64 * STAGE_LD * 4;
 constexpr int LDS_BYTES = LDS_BYTES_EPI > LDS_BYTES_MAIN ? LDS_BYTES_EPI : LDS_BYTES_MAIN;
 
-struct GemmP {
-  int M, N, K;
-  const char* A; long lda;
-  const char* W; long ldw;
-  const char* A2; long lda2;
-  const char* W2; long ldw2;
-  int K2, a2_col_block;
-  int tile_groups, rows_per_group;   // tile_groups > 1: M tiles never straddle a group
-  const int* group_adapter;
-  long w_adapter_stride, w2_adapter_stride;
-  const char* bias;
-  const char* group_bias; long ldgb;
-  const char* residual; long ldr;
-  int act; float out_scale;
-  char* C; long ldc;
-  // conv geometry (CONV only)
-  int Hin, Win, C1, C2, Hout, Wout, ksize, stride, upsample;
-  const char* X2;
-  int tiles_m, tiles_n;              // tiles_m is per group
-  int dbg;                           // ablation bits (tools only): 1 = no DMA in loop, 2 = no wait/barrier, 4 = no ds_read
-};
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <bool GLDS>
 OMG_DEV void stage16(const char* src, char* lds_wave_base, int lane, u32x4& hold) {
@@ -68,12 +45,6 @@ OMG_DEV void stage16(const char* src, char* lds_wave_base, int lane, u32x4& hold
     hold = *(const u32x4*)src;
   }
 }
-
-// Every GEMM/conv variant produces the same bits for the same problem (so that batching requests, which changes the
-// tile choice, does not change results): accumulators start at bias (+ the per-sample bias when a sample's rows are a
-// multiple of 256, i.e. no tile of any variant straddles samples), the K loop adds the products in the same order, and
-// the epilogue is [+ per-row group bias if it was not folded] -> SiLU (hardware reciprocal) -> fma(v, out_scale, residual).
-OMG_DEV bool fold_group_bias(const GemmP& p) { return p.group_bias != nullptr && p.rows_per_group % 256 == 0; }
 
 // non-transposed accumulators: acc[i][j][r] is column col0 + 32 j + l31
 template <typename T, int MT, int NT>
@@ -347,11 +318,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 // Large-tile kernels (v5 .. v8): 256-row block tiles, LDS stages of BK = 64 filled by LDS-DMA, raw s_barrier + explicit
 // s_waitcnt instead of __syncthreads.  LDS image per stage: rows of 128 B (8 chunks of 16 B), chunk ^= (row >> 1) & 7,
 // applied on the DMA source side and on the fragment read.
-template <int N> OMG_DEV void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 63, "vmcnt range");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 // Row-coalesced epilogue shared by the large-tile kernels: one 32-row slab of every wave per pass through a
 // [32][NT*32 + 4] fp32 staging area in LDS (bias / per-sample bias / SiLU / GEGLU / residual applied on 16-byte rows).
 // The wave's tile is (MT*32) x (NT*32) at (wm0, wn0) = (m0 + wm*MT*32, n0 + wn*NT*32).
@@ -441,194 +407,6 @@ OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, i
         }
       }
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Register-direct epilogue of the kernels that accumulate the TRANSPOSED tile (v6, v7: mfma(W fragment, A fragment)).
-// Register r of lane (l31, hi) of acc[i][j] is C[wm0 + 32 i + l31][wn0 + 32 j + 8 (r >> 2) + 4 hi + (r & 3)]: a lane owns
-// ONE output row per i and runs of 4 consecutive columns.  v_permlane32_swap trades the second run of a pair with the
-// partner lane (hi ^ 1), after which a lane holds 8 consecutive columns = one 16-byte store; loads of per-column /
-// per-element operands (bias, per-sample bias, residual) go through the same exchange the other way round.
-// No LDS, no barriers: the staging version cost 10-15 us per 256x256 tile (25-35 % of a K=1280 GEMM) — it serialised
-// 32 LDS round trips per wave and waited on vmcnt(0) (which also counts the stores in flight) at every residual load.
-template <typename T>
-OMG_DEV void swap_runs(unsigned (&q)[4]) {   // q[0..1] = run 0 (4 halves), q[2..3] = run 1
-  // v_permlane32_swap v_a, v_b exchanges lanes 32-63 of v_a with lanes 0-31 of v_b (both operands are written).
-  // Kept as inline asm with wait states on both sides, tied to the four registers by data dependence, so that neither the
-  // producer (v_cvt_pk_f16_f32) nor the consumer (buffer_store) can be scheduled against an instruction that writes both of
-  // its operands.  (The corruption first suspected here turned out to be the store-data hazard described in store_runs.)
-  asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 4"
-               : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
-}
-// All epilogue memory operations go through buffer descriptors with 32-bit offsets: an offset at or beyond num_records
-// makes a load return zeros and a store vanish, so row / column predicates are a v_cndmask on the offset instead of an
-// exec-mask branch around every access, and there is no 64-bit address arithmetic per access.
-constexpr int EPI_OOB = 0x7f000000;
-OMG_DEV __amdgpu_buffer_rsrc_t epi_rsrc(const char* base, long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base != nullptr ? (int)(bytes < 0x7effff00L ? bytes : 0x7effff00L) : 0, 0x00020000);
-}
-// 16 bytes at byte offset `off` (this lane's 8 consecutive columns) -> the 8 values in accumulator order (runs 0, 1)
-template <typename T>
-OMG_DEV void load_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, float (&f)[8]) {
-  const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0);
-  unsigned q[4] = {raw[0], raw[1], raw[2], raw[3]};
-  swap_runs<T>(q);
-  u32x4 sw = {q[0], q[1], q[2], q[3]};
-  unpack8<T>(sw, f);
-}
-template <typename T>
-OMG_DEV void store_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, const float (&f)[8]) {
-  u32x4 pk = pack8<T>(f);
-  unsigned q[4] = {pk[0], pk[1], pk[2], pk[3]};
-  swap_runs<T>(q);
-  u32x4 sw = {q[0], q[1], q[2], q[3]};
-  // The constant goes into the VGPR offset, never into an SGPR soffset: with `buffer_store_dwordx4 ..., s1 offen` the VALU
-  // instruction right behind the store overwrote dword 2 of the store data in the last lanes of each row before the
-  // store had read it (observed: the next row block's row index in the output; tools/debug_gemm_small.py).  hipcc adds
-  // the wait state only when soffset is an immediate.
-  __builtin_amdgcn_raw_buffer_store_b128(sw, rs, off + soff, 0, 0);
-}
-
-// Accumulators start at the bias instead of zero (one add per output saved in the epilogue, where a wave has no
-// partner to hide VALU latency behind).  Same register <-> element map as epilogue_direct.
-template <typename T, int MT, int NT>
-OMG_DEV bool acc_init_bias(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int m0, int wn0) {
-  const int hi = lane >> 5;
-  // the per-sample bias (conv + time embedding) is folded in as well under the rule shared by all variants
-  const bool fold_gb = fold_group_bias(p);
-  const __amdgpu_buffer_rsrc_t rsB = epi_rsrc(p.bias, (long)p.N * 2);
-  const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(fold_gb ? p.group_bias + (long)(m0 / p.rows_per_group) * p.ldgb * 2 : nullptr, (long)p.N * 2);
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      const int c = wn0 + j * 32 + pr * 16 + hi * 8;      // c >= N is beyond num_records: zeros
-      float f[8], g[8];
-      load_runs<T>(rsB, c * 2, 0, f);
-      load_runs<T>(rsG, c * 2, 0, g);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[i][j][pr * 8 + e] = f[e] + g[e];
-    }
-  return p.group_bias != nullptr && !fold_gb;     // true: the epilogue still has to add the per-row group bias
-}
-
-// State shared by the epilogue bodies: descriptors, the lane's column offsets and column predicates.
-template <int NT>
-struct EpiCtx {
-  __amdgpu_buffer_rsrc_t rsC, rsR, rsG;
-  int hi, l31, wm0, m_end;
-  int lane_col;                 // byte offset of the lane's unit (j = 0, pr = 0) inside a row
-  int voob[NT][2];              // 0 where the unit's columns are inside the matrix, EPI_OOB where they are not
-};
-
-// SiLU / per-row group bias / residual decided at run time inside the unit loop: the rare combinations
-template <typename T, int MT, int NT, bool RS, bool GENERIC>
-OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, bool has_gb) {
-  const float osc = p.out_scale;
-  const bool has_rs = GENERIC ? p.residual != nullptr : RS;
-  u32x4 rraw[2][NT][2];         // residual of row block i: the lane's NT*2 16-byte units, fetched one row block ahead
-#define OMG_FETCH_RES(i_, buf_)                                                                            \
-  do {                                                                                                     \
-    const int gm_ = cx.wm0 + (i_) * 32 + cx.l31;                                                           \
-    const int ro_ = gm_ < cx.m_end ? gm_ * (int)p.ldr * 2 + cx.lane_col : EPI_OOB;                         \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
-      _Pragma("unroll") for (int pr = 0; pr < 2; ++pr)                                                     \
-        rraw[buf_][j][pr] = __builtin_amdgcn_raw_buffer_load_b128(cx.rsR, ro_ | cx.voob[j][pr], (j * 32 + pr * 16) * 2, 0); \
-  } while (0)
-  if (has_rs) OMG_FETCH_RES(0, 0);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int gm = cx.wm0 + i * 32 + cx.l31;
-    const bool row_ok = gm < cx.m_end;
-    if (has_rs && i + 1 < MT) OMG_FETCH_RES(i + 1, (i + 1) & 1);
-    const int ro = row_ok ? gm * (int)p.ldc * 2 + cx.lane_col : EPI_OOB;
-    const int go = GENERIC && has_gb && row_ok ? ((gm / p.rows_per_group) * (int)p.ldgb) * 2 + cx.lane_col : EPI_OOB;
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[i][j][pr * 8 + e];
-        if constexpr (GENERIC) {
-          if (has_gb) {    // wave tile straddles samples (tiny feature maps only): per-row group bias, latency not hidden
-            float f[8];
-            load_runs<T>(cx.rsG, go | cx.voob[j][pr], (j * 32 + pr * 16) * 2, f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += f[e];
-          }
-          if (p.act == OMG_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
-          }
-        }
-        if (has_rs) {
-          const u32x4 rr = rraw[i & 1][j][pr];
-          unsigned q[4] = {rr[0], rr[1], rr[2], rr[3]};
-          swap_runs<T>(q);
-          u32x4 sw = {q[0], q[1], q[2], q[3]};
-          float rf[8];
-          unpack8<T>(sw, rf);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], osc, rf[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= osc;
-        }
-        store_runs<T>(cx.rsC, ro | cx.voob[j][pr], (j * 32 + pr * 16) * 2, v);
-        __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting every accumulator read to the top (spills)
-      }
-  }
-#undef OMG_FETCH_RES
-}
-
-template <typename T, int MT, int NT>
-OMG_DEV void epilogue_geglu(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, int lane_col_g) {
-  const float osc = p.out_scale;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int gm = cx.wm0 + i * 32 + cx.l31;
-    const int ro = gm < cx.m_end ? gm * (int)p.ldc * 2 + lane_col_g : EPI_OOB;
-#pragma unroll
-    for (int b = 0; b < NT / 2; ++b)
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = acc[i][2 * b][pr * 8 + e] * gelu_f(acc[i][2 * b + 1][pr * 8 + e]) * osc;
-        store_runs<T>(cx.rsC, ro | cx.voob[2 * b][pr], (b * 32 + pr * 16) * 2, o);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-  }
-}
-
-template <typename T, int MT, int NT>
-OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0, int m_end, bool has_gb) {
-  const bool geglu = p.act == OMG_ACT_GEGLU;
-  const int n_out = geglu ? p.N / 2 : p.N;
-  EpiCtx<NT> cx;
-  cx.hi = lane >> 5; cx.l31 = lane & 31; cx.wm0 = wm0; cx.m_end = m_end;
-  cx.rsC = epi_rsrc(p.C, ((long)(p.M - 1) * p.ldc + n_out) * 2);
-  cx.rsR = epi_rsrc(p.residual, ((long)(p.M - 1) * p.ldr + p.N) * 2);
-  cx.rsG = epi_rsrc(has_gb ? p.group_bias : nullptr, 0x7effff00L);
-  // the buffer bound only protects the end of the matrix, not the end of a row: per-unit column predicate, as an
-  // offset bit pattern that is OR-ed in (row offsets stay far below EPI_OOB's bits)
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr) cx.voob[j][pr] = (wn0 + j * 32 + pr * 16 + cx.hi * 8 < p.N && !(p.dbg & 1024)) ? 0 : EPI_OOB;   // dbg 1024 (tools): drop all stores
-  cx.lane_col = (wn0 + cx.hi * 8) * 2;
-  if (geglu) {
-    epilogue_geglu<T, MT, NT>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);   // GEGLU output is half as wide
-  } else if (has_gb || p.act == OMG_ACT_SILU) {
-    epilogue_rows<T, MT, NT, false, true>(p, acc, cx, has_gb);
-  } else if (p.residual != nullptr) {
-    epilogue_rows<T, MT, NT, true, false>(p, acc, cx, false);
-  } else {
-    epilogue_rows<T, MT, NT, false, false>(p, acc, cx, false);
   }
 }
 
@@ -841,12 +619,6 @@ __global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
   if (late) mma();
   __syncthreads();
   epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
-}
-
-// 16 bytes per lane, global -> LDS, through a buffer descriptor.  A non-template wrapper on purpose: with value-dependent
-// arguments the builtin's checks are deferred to instantiation time, where the host pass of hipcc silently drops the kernel.
-OMG_DEV void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, voff, soff, 0, 0);
 }
 
 // conv A-operand byte offset of one output pixel's tap inside the (logical, possibly 2x-upsampled) input image;

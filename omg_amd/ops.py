@@ -160,6 +160,72 @@ def gemm(a: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = Non
     return out
 
 
+class Mx8Tensor:
+    """An MX-fp8 quantised 2-D operand: ``q`` uint8 [rows, K] (OCP e4m3), ``scales`` int32 [K/128, s_ld] (four E8M0 bytes per
+    (row, 128-wide stage), stage-major — the layout omg_gemm_mx8 stages with one LDS-DMA per tile and stage)."""
+
+    __slots__ = ("q", "scales", "rows", "K")
+
+    def __init__(self, q: torch.Tensor, scales: torch.Tensor):
+        self.q, self.scales, self.rows, self.K = q, scales, q.shape[0], q.shape[1]
+
+
+def quant_mx8(x: torch.Tensor, out: Optional[Mx8Tensor] = None) -> Mx8Tensor:
+    """fp16 / bf16 [rows, K] (unit inner stride) -> :class:`Mx8Tensor` (omg_quant_mx8)."""
+    _dev(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    if K % 128 != 0:
+        raise L.OmgHipError("MX-fp8 operands need K % 128 == 0")
+    if out is None:
+        s_ld = (M + 3) // 4 * 4
+        out = Mx8Tensor(torch.empty((M, K), dtype=torch.uint8, device=x.device),
+                        torch.zeros((K // 128, s_ld), dtype=torch.int32, device=x.device))
+    assert out.q.shape == (M, K) and out.q.stride(1) == 1 and out.scales.shape[0] == K // 128
+    L.check(L.lib().omg_quant_mx8(_dt(x), x.data_ptr(), x.stride(0), M, K, out.q.data_ptr(), out.q.stride(0),
+                                  out.scales.data_ptr(), out.scales.stride(0), _stream()), "omg_quant_mx8")
+    return out
+
+
+def gemm_mx8(a: Mx8Tensor, w: Mx8Tensor, *, out_dtype: torch.dtype = torch.float16, bias: Optional[torch.Tensor] = None,
+             residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None,
+             out_scale: float = 1.0, groups: int = 1, w_group_adapter: Optional[torch.Tensor] = None,
+             n_per_adapter: Optional[int] = None) -> torch.Tensor:
+    """``out[M, N_out] = epi(dequant(a) @ dequant(w)^T)`` on the block-scaled fp8 MFMA (omg_gemm_mx8).
+
+    With ``w_group_adapter`` (int32 [groups]) ``w`` holds ``n_adapters * n_per_adapter`` rows — the per-sample weight slots of
+    the merged-LoRA mode stacked along the rows — and group g uses rows ``[id_g * n_per_adapter, (id_g + 1) * n_per_adapter)``."""
+    M, K = a.rows, a.K
+    assert w.K == K
+    N = n_per_adapter if w_group_adapter is not None else w.rows
+    n_out = N // 2 if act == L.ACT_GEGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=out_dtype, device=a.q.device)
+    assert out.stride(1) == 1 and out.shape == (M, n_out)
+    g = L.GemmMx8Args()
+    g.dtype = _dt(out)
+    g.M, g.N, g.K = M, N, K
+    g.A, g.lda, g.a_scale, g.sa_ld = a.q.data_ptr(), a.q.stride(0), a.scales.data_ptr(), a.scales.stride(0)
+    g.W, g.ldw, g.w_scale, g.sw_ld = w.q.data_ptr(), w.q.stride(0), w.scales.data_ptr(), w.scales.stride(0)
+    g.groups, g.rows_per_group = groups, M // groups
+    if w_group_adapter is not None:
+        g.group_adapter = w_group_adapter.data_ptr()
+        g.w_adapter_stride, g.sw_adapter_stride = N * w.q.stride(0), N
+    g.bias = _p(bias)
+    if residual is not None:
+        assert residual.stride(1) == 1
+        g.residual, g.ldr = residual.data_ptr(), residual.stride(0)
+    g.act, g.out_scale = act, out_scale
+    g.C, g.ldc = out.data_ptr(), out.stride(0)
+    if _PROF is not None:
+        t0 = _PROF.begin()
+        L.check(L.lib().omg_gemm_mx8(C.byref(g), _stream()), "omg_gemm_mx8")
+        _PROF.end("gemm_mx8", 2.0 * M * N * K, t0, ("mx8", M, N, K, 0, groups if w_group_adapter is not None else 1, act))
+        return out
+    L.check(L.lib().omg_gemm_mx8(C.byref(g), _stream()), "omg_gemm_mx8")
+    return out
+
+
 def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, upsample: bool = False,
            x2: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
            group_bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
