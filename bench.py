@@ -71,7 +71,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="images timed per GPU")
     ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up images per GPU")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp8"],
+                    help="fp8 = BASELINE configs[4]'s arithmetic: the transformer Linear layers on the MX-fp8 MFMA (omg_gemm_mx8), "
+                         "everything else fp16 as in the default mode; NOT the headline configuration")
     ap.add_argument("--scheduler", default="ddim", choices=["ddim", "euler"])
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,10 +97,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dt = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
 
     cfg = UNetConfig.tiny() if args.tiny else UNetConfig.sdxl()
     unet = UNet2DConditionModel(cfg, dtype=dt, device=dev).init_synthetic_(seed=0)
+    if args.dtype == "fp8":
+        unet.set_linear_precision("mx8")
     HW = cfg.sample_size * 8
     P = "a man and a woman walking on the street"
     ctl = pc.AttentionReplace([P, P], 50, cross_replace_steps={"default_": 1.0}, self_replace_steps=0.4,
@@ -152,7 +156,9 @@ def main():
 
     out = {"metric": "images/sec @ SDXL 1024^2 50-step, 2-concept mask fusion", "value": value, "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * el / args.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "fp8 (OCP MX e4m3 operands, fp32 accumulate) on the transformer Linear layers; fp16 elsewhere" if args.dtype == "fp8" else args.dtype,
+           "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: SDXL-base 1024x1024, %d %s steps, 2 concepts + 2 rank-64 LoRAs, masked "
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),
                       "global_batch": world * ips, "images_per_step_per_gpu": ips, "main_batch": 4 * ips, "concept_batch": 4 * ips, "accounting": "stage-2 only, as executed by the reference "
@@ -181,7 +187,8 @@ def main():
         n_p = args.denoise_steps - n_f
         def comb(kind, key):
             return (n_p * sp[kind][key] + n_f * sf[kind][key]) / 2.0
-        g_ms, g_fl, g_n = comb("gemm", "ms"), comb("gemm", "flops"), comb("gemm", "launches")
+        fam, peak = ("gemm_mx8", 5000.0) if args.dtype == "fp8" else ("gemm", PEAK_TFLOPS)
+        g_ms, g_fl, g_n = comb(fam, "ms"), comb(fam, "flops"), comb(fam, "launches")
         a_ms, a_fl = comb("attn", "ms"), comb("attn", "flops")
         ach = g_fl / (g_ms * 1e-3) / 1e12
         # HBM-side bytes cannot be counted from inside this process: the committed rocprofv3 --pmc measurement of the
@@ -196,13 +203,20 @@ def main():
                             % ((pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"]) / 1e9))
         except (OSError, KeyError, ValueError):
             pass
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel_v7 / gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)",
-                           "achieved": ach, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS, "traffic": traffic,
+        kname = ("gemm_mx8_kernel (transformer Linear layers, MX-fp8 operands on v_mfma_scale_f32_32x32x64_f8f6f4, per-sample weight slots)"
+                 if args.dtype == "fp8" else "gemm_kernel_v7 / gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)")
+        if args.dtype == "fp8":
+            traffic, traffic_note = None, "not measured for the MX-fp8 kernel"
+        out["roofline"] = {"bound": "mfma", "kernel": kname,
+                           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                            "traffic_note": traffic_note,
                            "launches_per_step": g_n, "avg_launch_us": 1e3 * g_ms / g_n, "avg_launch_gflop": g_fl / g_n / 1e9,
                            "gemm_ms_per_step": g_ms,
                            "sample": f"HIP events around each launch (eager), 2 plain + 2 fused denoising steps weighted {n_p}:{n_f} as in the timed workload",
                            "attn_kernel": {"achieved": a_fl / (a_ms * 1e-3) / 1e12, "ms_per_step": a_ms}}
+        if args.dtype == "fp8":      # the 16-bit GEMM family still runs the convolutions (and the K/V, embedding Linears)
+            c_ms, c_fl = comb("gemm", "ms"), comb("gemm", "flops")
+            out["roofline"]["fp16_gemm_family"] = {"achieved": c_fl / (c_ms * 1e-3) / 1e12, "ms_per_step": c_ms, "peak": PEAK_TFLOPS}
         if args.by_shape:
             rows = []
             for key in set(tp) | set(tf):

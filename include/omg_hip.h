@@ -206,6 +206,11 @@ int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, int C2,
                   float* workspace, void* Y, void* stream);
 int omg_layernorm(int dtype, const void* X, int64_t ldx, int M, int C, float eps,
                   const void* gamma, const void* beta, void* Y, int64_t ldy, void* stream);
+/* LayerNorm whose consumer is omg_gemm_mx8: the normalised row (rounded to `dtype` exactly as omg_layernorm stores it) is
+ * written as MX-fp8 bytes Q[M, C] + stage-major scale dwords (layout of omg_quant_mx8).  C % 128 == 0. */
+int omg_layernorm_mx8(int dtype, const void* X, int64_t ldx, int M, int C, float eps,
+                      const void* gamma, const void* beta, void* Q, int64_t ldq,
+                      void* scales, int s_ld, void* stream);
 
 /* ------------------------------------------------------------------------
  * Boundary convolutions (NCHW latents <-> NHWC features).

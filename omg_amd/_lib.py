@@ -92,6 +92,7 @@ SYMBOLS = {
     "omg_groupnorm_ws_floats": (c_i64, [c_i32, c_i32, c_i32]),
     "omg_groupnorm": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "omg_layernorm": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "omg_layernorm_mx8": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp]),
     "omg_conv_in": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "omg_conv_out": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "omg_timestep_embedding": (c_i32, [c_i32, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -63,6 +63,7 @@ class Attention(nn.Module):
         self.ip_kv_weight: Optional[torch.Tensor] = None
         self.ip_scale, self.ip_tokens = 1.0, 16
         self._ip_cache = None
+        self._mx8 = {}            # MX-fp8 images of the fused q|k|v weight (stack): "qkv", "qkv_slots"
 
     # ---- diffusers API
     def set_processor(self, processor) -> None:
@@ -99,6 +100,7 @@ class Attention(nn.Module):
     def invalidate_packed(self):
         self._qkv = self._kv = self._qkv_slots = self._kv_slots = None
         self._kv_cache = {}
+        self._mx8 = {}
         self._ip_cache = None
         bump_pointer_epoch()
 
@@ -138,10 +140,26 @@ class Attention(nn.Module):
             self._kv_slots = torch.cat([self.to_k.w_slots, self.to_v.w_slots], dim=1).contiguous()
         return self._kv_slots
 
-    def project_self(self, x: torch.Tensor):
-        """x (B,N,C) -> q, k views of one fused buffer, and V^T."""
+    def project_self(self, x):
+        """x (B,N,C) (a tensor, or the MX-fp8 output of the preceding LayerNorm) -> q, k views of one fused buffer, and V^T."""
         B, N, C = x.shape
         inner = self.inner_dim
+        if isinstance(x, ops.Mx8Tensor) or (self.to_q.mx8 and C % 128 == 0 and not self._has_lora()):
+            if self._has_lora():
+                raise L.OmgHipError("MX-fp8 activations cannot feed a segment-mode LoRA projection")
+            xq = x if isinstance(x, ops.Mx8Tensor) else ops.quant_mx8(x)
+            st = self._merged()
+            if st is not None:
+                if "qkv_slots" not in self._mx8:
+                    self._mx8["qkv_slots"] = ops.quant_mx8(self.qkv_slots().reshape(-1, C))
+                qkv = ops.gemm_mx8(xq, self._mx8["qkv_slots"], out_dtype=self.to_q.weight.dtype, groups=st.groups,
+                                   w_group_adapter=st.group_adapter, n_per_adapter=3 * inner)
+            else:
+                if "qkv" not in self._mx8:
+                    self._mx8["qkv"] = ops.quant_mx8(self.qkv_weight())
+                qkv = ops.gemm_mx8(xq, self._mx8["qkv"], out_dtype=self.to_q.weight.dtype)
+            qkv = qkv.view(B, N, 3 * inner)
+            return qkv[:, :, :inner], qkv[:, :, inner:2 * inner], ops.transpose_v(qkv[:, :, 2 * inner:], self.heads)
         if self._has_lora():
             q = self.to_q(x); k = self.to_k(x); v = self.to_v(x)
         else:
@@ -207,6 +225,8 @@ def _ip_branch(attn: Attention, q: torch.Tensor, o: torch.Tensor, ip_ctx: torch.
 
 
 def _to_tokens(attn, hidden_states):
+    if isinstance(hidden_states, ops.Mx8Tensor):
+        return hidden_states
     if hidden_states.dim() == 4:
         raise L.OmgHipError("4-D (NCHW) hidden_states are not produced by the SDXL transformer blocks; pass (B, N, C)")
     return hidden_states

@@ -65,6 +65,25 @@ OMG_DEV float erf_as(float x) {
 }
 OMG_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
+// ---- MX-fp8 quantisation helpers (gemm_mx8.hip, norm.hip): E8M0 scale of a 32-block and the e4m3 element cast.
+// Scale = the smallest power of two 2^e with amax / 2^e <= 448 (the e4m3 maximum): no element saturates.  Returns e + 127.
+OMG_DEV unsigned mx8_scale_exp(float amax) {
+  const float v = amax * (1.0f / 448.0f);
+  const unsigned bits = __builtin_bit_cast(unsigned, v);
+  int e = (int)(bits >> 23) - 127 + ((bits & 0x7fffffu) != 0 ? 1 : 0);
+  e = e < -127 ? -127 : (e > 127 ? 127 : e);
+  return (unsigned)(e + 127);
+}
+// 2^-(be - 127): be = 0 -> 2^127 (a block of zeros), be = 254 -> 2^-127 as the exponent field 0 would be 0.0, never reached by
+// fp16 / bf16 inputs (|x| / 448 < 2^127)
+OMG_DEV float mx8_inv_scale(unsigned be) { return __builtin_bit_cast(float, (254u - be) << 23); }
+OMG_DEV unsigned mx8_pack4(float a, float b, float c, float d) {     // four e4m3 bytes, round to nearest even (v_cvt_pk_fp8_f32: OCP on gfx950)
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned)r;
+}
+
 // 256 zero bytes any lane may source a padded (out-of-image / beyond-K) 16-byte chunk from
 extern __device__ __attribute__((aligned(256))) unsigned char omg_zero_page[256];
 

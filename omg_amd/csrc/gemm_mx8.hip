@@ -4,9 +4,11 @@
 //
 // The contraction runs on v_mfma_scale_f32_32x32x64_f8f6f4 — the only large-K low-precision MFMA of CDNA4 and the only way to
 // the 5 PFLOP/s fp8 rate (MI355X_MICROARCH.md; a non-scaled fp8 MFMA runs at the bf16 rate).  The instruction takes 64 K
-// elements per issue: a lane holds 32 consecutive K bytes of one row (lanes 0-31: k 0..31, lanes 32-63: k 32..63 of the
-// k-step) and ONE scale byte for them, so a lane's operand is exactly one MX block and the hardware applies 2^(sa + sb - 254)
-// to the block's partial dot product before it is accumulated in fp32.
+// elements per issue and applies 2^(sa + sb - 254) to each 32-wide block's partial dot product before the fp32 accumulation.
+// Operand layout, MEASURED on the part (tools/mx8_probe.py: one non-zero byte walked through K against per-block scales):
+// lane (row i = lane & 31, half h = lane >> 5) holds in registers 0-3 the bytes k = 16 h .. 16 h + 15 and in registers 4-7 the
+// bytes k = 32 + 16 h .. 32 + 16 h + 15 of the k-step — i.e. block 0 (k 0..31) is registers 0-3 of BOTH lane halves and block 1
+// registers 4-7 — while the scale of block b of row i is the selected byte of the scale register of lane i + 32 b.
 //
 // Kernel = the structure of gemm_kernel_v7 (gemm.hip), at the same BYTES per stage: 256x256 output tile on four waves
 // (128x128 per wave, 256 accumulator registers), double-buffered LDS stages of 128 bytes of K per row (= 128 fp8 elements,
@@ -17,8 +19,8 @@
 // Scales travel with the stage: they are stored STAGE-MAJOR as one dword per (row, stage) — the four E8M0 bytes of the
 // row's four 32-blocks inside that 128-wide stage — S[K/128][rows] (uint32), so the 256 rows of a tile are 1 KiB contiguous
 // for a given stage = ONE LDS-DMA instruction per operand per stage (wave 0: A scales, wave 1: W scales), and a lane fetches
-// its row's dword with a ds_read_b32.  After `>> 8*hi` byte 0 / byte 2 of that dword are the lane's scales for k-step 0 / 1
-// (op_sel picks the byte).  The quantiser (quant_mx8_kernel, below) writes this layout; weights are quantised once.
+// its row's dword with a ds_read_b32.  After `>> 8*hi` byte 0 / byte 2 of that dword are the scales lane half hi has to supply
+// for k-step 0 / 1 (blocks hi and 2 + hi of the stage; op_sel picks the byte).  The quantiser (quant_mx8_kernel, below) writes this layout; weights are quantised once.
 //
 // Epilogue, tile -> CU mapping, per-sample weight slots, bias folding: shared with v7 (gemm_epilogue.h).  The output and the
 // bias / residual operands stay fp16 / bf16.
@@ -114,14 +116,15 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
   f32x16 acc[MT][NT];
   const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * 128);
 
-  // ---- fragment addressing.  k-step ks, lane half hi -> the 32 bytes at chunks c0 = 4 ks + 2 hi and c0 + 1 of the row,
-  // at their swizzled positions (chunk ^ ((row >> 1) & 7); tile bases are multiples of 16 rows, so the term is the lane's).
+  // ---- fragment addressing.  k-step ks, lane half hi -> registers 0-3 from the 16-byte chunk 4 ks + hi (block 2 ks), registers
+  // 4-7 from chunk 4 ks + 2 + hi (block 2 ks + 1), at their swizzled positions (chunk ^ ((row >> 1) & 7); tile bases are
+  // multiples of 16 rows, so the term is the lane's).  The lane's scale byte is that of block 2 ks + hi.
   const int sw = (l31 >> 1) & 7;
   int foff[2][2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) foff[ks][h] = l31 * 128 + (((ks * 4 + hi * 2 + h) ^ sw) << 4);
+    for (int h = 0; h < 2; ++h) foff[ks][h] = l31 * 128 + (((ks * 4 + h * 2 + hi) ^ sw) << 4);
   const int aB = wm * (128 * 128), bB = MX_TILE + wn * (128 * 128);
   const int sAoff = MX_SC + (wm * 128 + l31) * 4, sWoff = MX_SC + 1024 + (wn * 128 + l31) * 4;
   const int sshift = hi * 8;
@@ -228,14 +231,6 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
 // A workgroup takes 32 rows; per iteration one 128-wide stage: thread t -> row t / 8, elements 16 (t % 8) .. + 15, so two
 // neighbouring lanes share a 32-block (one DPP exchange for the amax), a row's 128 output bytes are one whole cache line and
 // the 32 rows' scale dwords of the stage are one more.
-OMG_DEV unsigned mx_scale_exp(float amax) {       // biased E8M0 exponent
-  const float v = amax * (1.0f / 448.0f);
-  const unsigned bits = __float_as_uint(v);
-  int e = (int)(bits >> 23) - 127 + ((bits & 0x7fffffu) != 0 ? 1 : 0);
-  e = e < -127 ? -127 : (e > 127 ? 127 : e);
-  return (unsigned)(e + 127);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const char* x, long ldx, int M, int K, char* q, long ldq, unsigned* s, int s_ld) {
   const int t = threadIdx.x;
@@ -260,16 +255,11 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const char* x, long ldx,
 #pragma unroll
     for (int e = 0; e < 16; ++e) amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
     amax = __builtin_fmaxf(amax, __shfl_xor(amax, 1));
-    const unsigned be = mx_scale_exp(amax);
-    const float inv = __uint_as_float((254u - be) << 23);      // 2^-(be - 127); be = 0 -> 2^127, be = 254 -> 2^-127 (subnormal source only)
+    const unsigned be = mx8_scale_exp(amax);
+    const float inv = mx8_inv_scale(be);
     unsigned o[4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      int r = 0;
-      r = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * d] * inv, f[4 * d + 1] * inv, r, false);
-      r = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * d + 2] * inv, f[4 * d + 3] * inv, r, true);
-      o[d] = (unsigned)r;
-    }
+    for (int d = 0; d < 4; ++d) o[d] = mx8_pack4(f[4 * d] * inv, f[4 * d + 1] * inv, f[4 * d + 2] * inv, f[4 * d + 3] * inv);
     *(u32x4*)(qr + (long)st * 128) = u32x4{o[0], o[1], o[2], o[3]};
     // the stage's four scale bytes sit in lanes part = 0, 2, 4, 6 of the row: gather them into lane part = 0
     unsigned sc = be;
@@ -280,7 +270,7 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const char* x, long ldx,
   }
 }
 
-int g_mx_d1 = 8;
+int g_mx_d1 = 12;      // measured best of 8 / 12 / 16 on the UNet's shapes (profiles/r02_mx8_bench.log)
 
 template <typename T>
 int launch_mx8(GemmP p, hipStream_t s, int mrows) {

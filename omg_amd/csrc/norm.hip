@@ -187,7 +187,100 @@ __global__ __launch_bounds__(256) void ln_kernel(const char* X, long ldx, int M,
   }
 }
 
+// LayerNorm whose output goes straight to an MX-fp8 GEMM (omg_gemm_mx8): the normalised row never exists in 16 bits.  Same
+// statistics and affine arithmetic as ln_kernel; a lane's 8 outputs are a quarter of a 32-block (amax over 4 adjacent lanes),
+// 16 adjacent lanes are one 128-wide stage = one scale dword S[stage][row].  C % 128 == 0.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_mx8_kernel(const char* X, long ldx, int M, int C, float eps, const char* gamma,
+                                                     const char* beta, char* Q, long ldq, unsigned* S, int s_ld) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= M) return;
+  const int nvec = C >> 3;
+  float x[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int vec = lane + v * 64;
+    if (vec < nvec) {
+      unpack8<T>(*(const u32x4*)(X + ((long)row * ldx + vec * 8) * 2), x[v]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += x[v][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[v][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int vec = lane + v * 64;
+    if (vec < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = x[v][e] - mean; q += d * d; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int vec = lane + v * 64;             // nvec is a multiple of 16: a group of 16 lanes is valid or invalid as a whole
+    float y[8];
+    float amax = 0.f;
+    if (vec < nvec) {
+      float ga[8], be[8];
+      unpack8<T>(*(const u32x4*)(gamma + (long)vec * 16), ga);
+      unpack8<T>(*(const u32x4*)(beta + (long)vec * 16), be);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // the value the 16-bit LayerNorm would have stored: the quantiser then sees exactly what omg_quant_mx8 would see
+        y[e] = (float)(T)((x[v][e] - mean) * rstd * ga[e] + be[e]);
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(y[e]));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = 0.f;
+    }
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 1));
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 2));
+    const unsigned be_ = mx8_scale_exp(amax);
+    const float inv = mx8_inv_scale(be_);
+    unsigned sc = be_;
+    sc |= __shfl_down(be_, 4) << 8;
+    sc |= __shfl_down(be_, 8) << 16;
+    sc |= __shfl_down(be_, 12) << 24;
+    if (vec < nvec) {
+      *(u32x2*)(Q + (long)row * ldq + vec * 8) = u32x2{mx8_pack4(y[0] * inv, y[1] * inv, y[2] * inv, y[3] * inv),
+                                                        mx8_pack4(y[4] * inv, y[5] * inv, y[6] * inv, y[7] * inv)};
+      if ((lane & 15) == 0) S[(long)(vec >> 4) * s_ld + row] = sc;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int omg_layernorm_mx8(int dtype, const void* X, int64_t ldx, int M, int C, float eps, const void* gamma, const void* beta,
+                                 void* Q, int64_t ldq, void* scales, int s_ld, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_layernorm_mx8: dtype");
+  OMG_REQUIRE(X && gamma && beta && Q && scales, "omg_layernorm_mx8: null operand");
+  OMG_REQUIRE(C % 128 == 0 && C <= 2048 && ldx % 8 == 0 && ldq % 16 == 0 && s_ld >= M && s_ld % 4 == 0, "omg_layernorm_mx8: C % 128, C <= 2048, ldx % 8, ldq % 16, s_ld");
+  if (M == 0) return OMG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((M + 3) / 4);
+  const int nv = (C / 8 + 63) / 64;
+#define LNQ_LAUNCH(TT, NVV) OMG_LAUNCH((ln_mx8_kernel<TT, NVV>), grid, dim3(256), 0, s, (const char*)X, (long)ldx, M, C, eps, (const char*)gamma, (const char*)beta, (char*)Q, (long)ldq, (unsigned*)scales, s_ld)
+  if (dtype == OMG_F16) {
+    switch (nv) { case 1: LNQ_LAUNCH(f16, 1); break; case 2: LNQ_LAUNCH(f16, 2); break; case 3: LNQ_LAUNCH(f16, 3); break; default: LNQ_LAUNCH(f16, 4); }
+  } else {
+    switch (nv) { case 1: LNQ_LAUNCH(bf16, 1); break; case 2: LNQ_LAUNCH(bf16, 2); break; case 3: LNQ_LAUNCH(bf16, 3); break; default: LNQ_LAUNCH(bf16, 4); }
+  }
+#undef LNQ_LAUNCH
+  return omg_check_launch("layernorm_mx8");
+}
 
 extern "C" int64_t omg_groupnorm_ws_floats(int B, int groups, int HW) {
   (void)HW;

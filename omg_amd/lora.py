@@ -141,6 +141,8 @@ class LoraBank:
         for m in self.unet.modules():
             if isinstance(m, (GEGLU, Attention)):
                 m.invalidate_packed()
+            elif isinstance(m, Linear):
+                m.invalidate_mx8_slots()
 
     def clear(self) -> None:
         for m in self.unet.modules():

@@ -83,6 +83,34 @@ class Linear(_Packed):
         # merged mode: [1 + slots, out, in] = base weight followed by W + scale*B_s A_s per slot
         self.w_slots: Optional[torch.Tensor] = None
         self.lora_state: Optional[LoraState] = None   # set per forward by the UNet
+        # MX-fp8 mode (UNet2DConditionModel.set_linear_precision): operands quantised to e4m3 with per-32 block scales, product on
+        # the scaled MFMA (omg_gemm_mx8).  Quantised weight images live in ``_packed`` ("mx8_w", "mx8_slots").
+        self.mx8 = False
+
+    def invalidate_mx8_slots(self) -> None:
+        if self._packed.pop("mx8_slots", None) is not None:
+            bump_pointer_epoch()
+
+    def _mx8_ok(self) -> bool:
+        st = self.lora_state
+        return self.in_features % 128 == 0 and not (st is not None and not st.merged and self.lora_down is not None)
+
+    def _forward_mx8(self, x, residual, act):
+        xq = x if isinstance(x, ops.Mx8Tensor) else ops.quant_mx8(x)
+        shp = xq.shape
+        r2 = residual.reshape(-1, self.out_features) if residual is not None else None
+        st = self.lora_state
+        dt = self.weight.dtype
+        if st is not None and st.merged and self.w_slots is not None:
+            if "mx8_slots" not in self._packed:
+                self._packed["mx8_slots"] = ops.quant_mx8(self.w_slots.reshape(-1, self.in_features))
+            y = ops.gemm_mx8(xq, self._packed["mx8_slots"], out_dtype=dt, bias=self.bias, residual=r2, act=act, groups=st.groups,
+                             w_group_adapter=st.group_adapter, n_per_adapter=self.out_features)
+        else:
+            if "mx8_w" not in self._packed:
+                self._packed["mx8_w"] = ops.quant_mx8(self.weight.data)
+            y = ops.gemm_mx8(xq, self._packed["mx8_w"], out_dtype=dt, bias=self.bias, residual=r2, act=act)
+        return y.view(*shp[:-1], y.shape[-1])
 
     def _lora(self, x2: torch.Tensor) -> Optional[ops.LoraSpec]:
         st = self.lora_state
@@ -93,6 +121,10 @@ class Linear(_Packed):
 
     def forward(self, x: torch.Tensor, scale=None, *, residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE,
                 group_bias: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
+        if isinstance(x, ops.Mx8Tensor) or (self.mx8 and group_bias is None and self._mx8_ok()):
+            if group_bias is not None or not self._mx8_ok():
+                raise L.OmgHipError("an MX-fp8 activation reached a Linear layer that cannot run in MX-fp8")
+            return self._forward_mx8(x, residual, act)
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         r2 = residual.reshape(-1, self.out_features) if residual is not None else None
@@ -130,7 +162,26 @@ class GEGLU(_Packed):
     def invalidate_packed(self):
         super().invalidate_packed()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward_mx8(self, x) -> torch.Tensor:
+        xq = x if isinstance(x, ops.Mx8Tensor) else ops.quant_mx8(x)
+        shp = xq.shape
+        pk = self._packed_w()
+        st = self.proj.lora_state
+        dt = self.proj.weight.dtype
+        if st is not None and st.merged and "w_slots" in pk:
+            if "mx8_slots" not in pk:
+                pk["mx8_slots"] = ops.quant_mx8(pk["w_slots"].reshape(-1, self.proj.in_features))
+            y = ops.gemm_mx8(xq, pk["mx8_slots"], out_dtype=dt, bias=pk["b"], act=L.ACT_GEGLU, groups=st.groups,
+                             w_group_adapter=st.group_adapter, n_per_adapter=self.proj.out_features)
+        else:
+            if "mx8_w" not in pk:
+                pk["mx8_w"] = ops.quant_mx8(pk["w"])
+            y = ops.gemm_mx8(xq, pk["mx8_w"], out_dtype=dt, bias=pk["b"], act=L.ACT_GEGLU)
+        return y.view(*shp[:-1], y.shape[-1])
+
+    def forward(self, x) -> torch.Tensor:
+        if isinstance(x, ops.Mx8Tensor) or (self.proj.mx8 and self.proj._mx8_ok()):
+            return self._forward_mx8(x)
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         pk = self._packed_w()
@@ -186,7 +237,10 @@ class LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
         self.bias = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, mx8: bool = False):
+        """``mx8=True``: the normalised rows as an :class:`omg_amd.ops.Mx8Tensor` for an MX-fp8 Linear (never stored in 16 bits)."""
+        if mx8 and x.shape[-1] % 128 == 0:
+            return ops.layernorm_mx8(x, self.weight, self.bias, self.eps)
         return ops.layernorm(x, self.weight, self.bias, self.eps)
 
 

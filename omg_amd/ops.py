@@ -164,23 +164,30 @@ class Mx8Tensor:
     """An MX-fp8 quantised 2-D operand: ``q`` uint8 [rows, K] (OCP e4m3), ``scales`` int32 [K/128, s_ld] (four E8M0 bytes per
     (row, 128-wide stage), stage-major — the layout omg_gemm_mx8 stages with one LDS-DMA per tile and stage)."""
 
-    __slots__ = ("q", "scales", "rows", "K")
+    __slots__ = ("q", "scales", "rows", "K", "shape")
 
-    def __init__(self, q: torch.Tensor, scales: torch.Tensor):
+    def __init__(self, q: torch.Tensor, scales: torch.Tensor, shape=None):
         self.q, self.scales, self.rows, self.K = q, scales, q.shape[0], q.shape[1]
+        self.shape = tuple(shape) if shape is not None else (q.shape[0], q.shape[1])      # logical shape (..., K) of the activation
+
+    @property
+    def device(self):
+        return self.q.device
 
 
 def quant_mx8(x: torch.Tensor, out: Optional[Mx8Tensor] = None) -> Mx8Tensor:
-    """fp16 / bf16 [rows, K] (unit inner stride) -> :class:`Mx8Tensor` (omg_quant_mx8)."""
+    """fp16 / bf16 [..., K] (rows with one common stride, unit inner stride) -> :class:`Mx8Tensor` (omg_quant_mx8)."""
     _dev(x)
-    assert x.dim() == 2 and x.stride(1) == 1
+    shape = x.shape
+    x = x.reshape(-1, shape[-1])
+    assert x.stride(1) == 1
     M, K = x.shape
     if K % 128 != 0:
         raise L.OmgHipError("MX-fp8 operands need K % 128 == 0")
     if out is None:
         s_ld = (M + 3) // 4 * 4
         out = Mx8Tensor(torch.empty((M, K), dtype=torch.uint8, device=x.device),
-                        torch.zeros((K // 128, s_ld), dtype=torch.int32, device=x.device))
+                        torch.zeros((K // 128, s_ld), dtype=torch.int32, device=x.device), shape)
     assert out.q.shape == (M, K) and out.q.stride(1) == 1 and out.scales.shape[0] == K // 128
     L.check(L.lib().omg_quant_mx8(_dt(x), x.data_ptr(), x.stride(0), M, K, out.q.data_ptr(), out.q.stride(0),
                                   out.scales.data_ptr(), out.scales.stride(0), _stream()), "omg_quant_mx8")
@@ -384,6 +391,21 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     L.check(L.lib().omg_layernorm(_dt(x), x2.data_ptr(), x2.stride(0), x2.shape[0], Cc, eps, gamma.data_ptr(),
                                   beta.data_ptr(), y.data_ptr(), y.stride(0), _stream()), "omg_layernorm")
     return y.view(x.shape)
+
+
+def layernorm_mx8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> "Mx8Tensor":
+    """LayerNorm straight into MX-fp8 (bytes + block scales): the input of an MX-fp8 Linear; rows = all leading dims."""
+    _dev(x)
+    Cc = x.shape[-1]
+    x2 = x.reshape(-1, Cc)
+    assert x2.stride(1) == 1
+    M = x2.shape[0]
+    out = Mx8Tensor(torch.empty((M, Cc), dtype=torch.uint8, device=x.device),
+                    torch.empty((Cc // 128, (M + 3) // 4 * 4), dtype=torch.int32, device=x.device), x.shape)
+    L.check(L.lib().omg_layernorm_mx8(_dt(x), x2.data_ptr(), x2.stride(0), M, Cc, eps, gamma.data_ptr(), beta.data_ptr(),
+                                      out.q.data_ptr(), out.q.stride(0), out.scales.data_ptr(), out.scales.stride(0), _stream()),
+            "omg_layernorm_mx8")
+    return out
 
 
 def conv_in(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:

@@ -134,9 +134,11 @@ class BasicTransformerBlock(nn.Module):
         return attn(x, encoder_hidden_states=ehs, **kw) + h      # foreign processor: protocol only
 
     def forward(self, h, ehs, kw):
-        h = self._attend(self.attn1, self.norm1(h), h, None, kw)
-        h = self._attend(self.attn2, self.norm2(h), h, ehs, kw)
-        return self.ff(self.norm3(h), residual=h)
+        # MX-fp8 mode: the three LayerNorms write their consumer GEMM's operand format directly (bytes + block scales)
+        fused = getattr(self.attn1.processor, "supports_fused_residual", False) and getattr(self.attn2.processor, "supports_fused_residual", False)
+        h = self._attend(self.attn1, self.norm1(h, mx8=fused and self.attn1.to_q.mx8 and not self.attn1._has_lora()), h, None, kw)
+        h = self._attend(self.attn2, self.norm2(h, mx8=fused and self.attn2.to_q.mx8 and self.attn2.to_q._mx8_ok()), h, ehs, kw)
+        return self.ff(self.norm3(h, mx8=self.ff.net[0].proj.mx8 and self.ff.net[0].proj._mx8_ok()), residual=h)
 
 
 class Transformer2DModel(nn.Module):
@@ -351,6 +353,24 @@ class UNet2DConditionModel(nn.Module):
             p.data.copy_(w.to(p.dtype))
         self.invalidate_packed()
         return self
+
+    # ------------------------------------------------------------------ precision of the transformer Linear layers
+    def set_linear_precision(self, mode: str = "fp16") -> None:
+        """``"mx8"``: every Linear inside the transformer blocks whose K is a multiple of 128 (q|k|v, to_q, to_out, GEGLU, FF-out,
+        proj_in / proj_out: 66 % of the UNet's FLOPs) runs on the block-scaled fp8 MFMA with OCP MX operands (omg_gemm_mx8);
+        activations are quantised by the producing LayerNorm or by omg_quant_mx8.  Kept in 16 bits, as SURVEY §7.3 item 8 asks:
+        conv_in / conv_out, every convolution, the time / text embeddings and their projections, the cross-attention K / V
+        projections of the (constant) text context, all norms' statistics, attention itself.  ``"fp16"`` (the name covers bf16
+        storage too) restores the 16-bit GEMMs."""
+        if mode not in ("fp16", "mx8"):
+            raise ValueError(mode)
+        on = mode == "mx8"
+        for name, m in self.named_modules():
+            if isinstance(m, Linear):
+                in_block = ".attentions." in name and not (name.endswith(".to_k") or name.endswith(".to_v")) or \
+                           (".attentions." in name and ".attn1." in name)
+                m.mx8 = on and in_block and m.in_features % 128 == 0
+        self.linear_precision = mode
 
     # ------------------------------------------------------------------ LoRA selection
     def set_lora_state(self, state: Optional[LoraState]) -> None:

@@ -143,3 +143,63 @@ def test_precision_report_fp16_vs_mx8(dev):
     e16, e8 = (y16 - ref).pow(2).mean().sqrt().item() / rms, (y8 - ref).pow(2).mean().sqrt().item() / rms
     print(f"relative rms error vs fp32: fp16 path {e16:.2e}, MX-fp8 path {e8:.2e} (max |d| / rms {(y8 - ref).abs().max().item() / rms:.2e})")
     assert e16 < 1e-3 and e8 < 6e-2
+
+
+def test_layernorm_mx8_equals_layernorm_then_quantise(dev):
+    """The fused LayerNorm -> MX-fp8 kernel rounds to the 16-bit value omg_layernorm would have stored before quantising, so it
+    must equal the two-kernel sequence bit for bit."""
+    for dtype in (torch.float16, torch.bfloat16):
+        for (M, C) in [(300, 1280), (1030, 640), (77, 128)]:
+            x = gen((M, C), 21, scale=3.0, dtype=dtype).to(dev)
+            g, b = gen((C,), 22, dtype=dtype).to(dev) + 1, gen((C,), 23, dtype=dtype).to(dev)
+            fused = ops.layernorm_mx8(x, g, b, 1e-5)
+            two = ops.quant_mx8(ops.layernorm(x, g, b, 1e-5))
+            assert torch.equal(fused.q, two.q) and torch.equal(fused.scales[:, :M], two.scales[:, :M])
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_unet_in_mx8_mode_vs_fp16_mode_and_oracle(dev, lora):
+    """Module-level Δ of the MX-fp8 Linear path (SURVEY §7.1 P5 'tolerance report per precision'): the tiny SDXL-topology UNet with
+    widths raised to multiples of 128 so that every transformer Linear qualifies; fp16 path and MX-fp8 path vs the fp32 oracle."""
+    from omg_amd.unet import UNet2DConditionModel, UNetConfig
+    from omg_amd.lora import LoraAdapter, LoraBank
+    from omg_amd.pipeline import ConceptModels
+    from oracle import unet as ou
+    kw = dict(sample_size=16, block_out_channels=(128, 256, 512), transformer_layers_per_block=(1, 1, 2), attention_head_dim=(2, 4, 8),
+              cross_attention_dim=128, addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32)
+    cfg, ocfg = UNetConfig(**kw), ou.UNetConfig(**kw)
+    dtype = torch.float16
+    sd = ou.init_state_dict(ocfg, seed=0, dtype=dtype)
+    unet = UNet2DConditionModel(cfg, dtype=dtype, device=dev)
+    unet.load_state_dict({k: v.to(dtype) for k, v in sd.items()})
+    B = 4
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 4, 16, 16, generator=g)
+    ctx = torch.randn(B, 77, 128, generator=g).to(dtype).float()
+    te = torch.randn(B, 64, generator=g).to(dtype).float()
+    tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]]).repeat(B, 1)
+    olora, state = None, None
+    if lora:
+        names = ou.lora_target_names(ocfg)
+        ow, olora = ou.make_lora(ocfg, names, rank=8, seed=100, scale=0.8, dtype=dtype)
+        bank = LoraBank(unet, [LoraAdapter("c0", {k: (a.to(dev), b.to(dev)) for k, (a, b) in ow.items()})])
+        bank.build([(("c0", 1.0),)], scale=0.8, mode="merged")
+        state = ConceptModels(unet, bank).lora_state([1] * B, merged=True)
+    ref = ou.unet_forward(sd, ocfg, x, 500.0, ctx, te, tid, lora=olora)
+    out = {}
+    for mode in ("fp16", "mx8"):
+        unet.set_linear_precision(mode)
+        unet.set_lora_state(state)
+        out[mode] = unet(x.to(dev), 500.0, encoder_hidden_states=ctx.to(dev).to(dtype),
+                         added_cond_kwargs={"text_embeds": te.to(dev).to(dtype), "time_ids": tid.to(dev)})[0].float().cpu()
+        unet.set_lora_state(None)
+    unet.set_linear_precision("fp16")
+    rms = ref.pow(2).mean().sqrt().item()
+    e16 = (out["fp16"] - ref).abs().max().item() / rms
+    e8 = (out["mx8"] - ref).abs().max().item() / rms
+    e8r = (out["mx8"] - ref).pow(2).mean().sqrt().item() / rms
+    print(f"UNet forward (lora={lora}) vs fp32 oracle, max |d| / rms: fp16 path {e16:.2e}, MX-fp8 Linear path {e8:.2e} (rms error {e8r:.2e}); "
+          f"fp8 vs fp16 path {(out['mx8'] - out['fp16']).abs().max().item() / rms:.2e}")
+    assert e16 < 3e-2
+    assert e8 < 0.5 and e8r < 0.1        # measured: see profiles/r02_mx8_precision.txt
+    assert not torch.equal(out["mx8"], out["fp16"])

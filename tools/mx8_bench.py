@@ -29,14 +29,16 @@ def main():
         M = B * hw
         x = torch.randn(M, K, device=dev, dtype=dt)
         w = torch.randn(N, K, device=dev, dtype=dt)
-        out = torch.empty(M, N, device=dev, dtype=dt)
+        geglu = "geglu" in tag
+        act = L.ACT_GEGLU if geglu else L.ACT_NONE
+        out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=dt)
         fl = 2.0 * M * N * K
-        t16 = timeit(lambda: ops.gemm(x, w, out=out))
+        t16 = timeit(lambda: ops.gemm(x, w, out=out, act=act))
         xq, wq = ops.quant_mx8(x), ops.quant_mx8(w)
         row = []
         for d1 in (8, 12, 16):
             lib.omg_debug_set_mx8_split(d1)
-            row.append(fl / timeit(lambda: ops.gemm_mx8(xq, wq, out=out)) / 1e9)
+            row.append(fl / timeit(lambda: ops.gemm_mx8(xq, wq, out=out, act=act)) / 1e9)
         lib.omg_debug_set_mx8_split(8)
         tq = timeit(lambda: ops.quant_mx8(x, out=xq))
         print(f"{tag:12s} M={M:7d} N={N:5d} K={K:5d}: {fl / t16 / 1e9:7.0f} | " + " ".join(f"{r:7.0f}" for r in row) + f" | {tq * 1e3:7.1f} us ({M * K * 3 / tq / 1e6:6.0f} GB/s)")
