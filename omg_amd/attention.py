@@ -96,6 +96,10 @@ class Attention(nn.Module):
         q, k = query.contiguous(), key.contiguous()
         return ops.attn_probs(q, k, 1, self.scale)      # batch' = B*heads, one head of 64
 
+    def _apply(self, fn, *a, **k):        # .to() / .half(): the fused weight images and K/V caches belong to the old storage
+        self.invalidate_packed()
+        return super()._apply(fn, *a, **k)
+
     # ---- fused projections
     def invalidate_packed(self):
         self._qkv = self._kv = self._qkv_slots = self._kv_slots = None

@@ -149,13 +149,6 @@ def _tokenize(tok):
     return fn
 
 
-def _to_pil(images01: torch.Tensor) -> list:
-    """``image_processor.postprocess(image, output_type="pil")``: (n, 3, H, W) in [0, 1] -> PIL images."""
-    from PIL import Image
-    arr = (images01.detach().float().cpu().permute(0, 2, 3, 1).numpy() * 255).round().astype("uint8")
-    return [Image.fromarray(a) for a in arr]
-
-
 def _cond_image_tensor(image, height: int, width: int) -> torch.Tensor:
     """``prepare_image``: PIL / array / tensor (or a list of them, one per sample of the request) -> (1, 3, H, W) in [0, 1]."""
     def one(im):
@@ -268,13 +261,8 @@ class LoraMultiConceptPipeline(_PipeMixin, _LoraPipe):
             h = height or self.unet.config.sample_size * self.vae_scale_factor
             w = width or self.unet.config.sample_size * self.vae_scale_factor
             image = _cond_image_tensor(image, h, w)
-        out = _LoraPipe.__call__(self, prompt=prompt, prompt_2=prompt_2, image=image, height=height, width=width,
-                                 output_type="latent" if output_type == "latent" else "pt", return_dict=True, **kw).images
-        if output_type == "pil":
-            out = _to_pil(out)
-        elif output_type == "np":
-            out = out.float().cpu().permute(0, 2, 3, 1).numpy()
-        return StableDiffusionXLPipelineOutput(images=out) if return_dict else (out,)
+        return _LoraPipe.__call__(self, prompt=prompt, prompt_2=prompt_2, image=image, height=height, width=width,
+                                  output_type=output_type, return_dict=return_dict, **kw)
 
 
 # ------------------------------------------------------------------------------------------------ InstantID
@@ -378,9 +366,5 @@ class InstantidMultiConceptPipeline(_PipeMixin, _InstantidPipe):
             image = _cond_image_tensor(image, h, w)
         if t2i_image is not None:
             t2i_image = _cond_image_tensor(t2i_image, h, w)
-        out = _InstantidPipe.__call__(self, image=image, t2i_image=t2i_image, height=height, width=width, concept_models=concept_models,
-                                      stage=stage, output_type="latent" if output_type == "latent" else "pt", return_dict=True,
-                                      **extra, **kw).images
-        if output_type == "pil":
-            out = _to_pil(out)
-        return StableDiffusionXLPipelineOutput(images=out) if return_dict else (out,)
+        return _InstantidPipe.__call__(self, image=image, t2i_image=t2i_image, height=height, width=width, concept_models=concept_models,
+                                       stage=stage, output_type=output_type, return_dict=return_dict, **extra, **kw)

@@ -9,7 +9,7 @@ pass on ``latent_model_input[3:4]`` duplicated (:583-585), fusion for ``i > 15 a
 
 Text encoders and the VAE are separate modules (rows N4 / N1 of SURVEY §8f).  Without them the call takes ``prompt_embeds`` /
 pooled embeddings (the reference computes them at :315-347 and passes them on) and returns latents
-(``output_type="latent"``), or decoded images in [0, 1] when the pipeline was built with
+(``output_type="latent"``), or decoded images (``"pil"``, the reference's default, / ``"pt"`` / ``"np"``) when the pipeline was built with
 ``vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents`` (row N1; the reference's tail at :635-661);
 ``prompt=`` works when the pipeline was built with ``encode_prompt=omg_amd.text_encoder.make_encode_prompt(...)``.
 
@@ -168,7 +168,7 @@ class LoraMultiConceptPipeline:
                  num_inference_steps: int = 50, guidance_scale: float = 5.0, negative_prompt=None, negative_prompt_2=None,
                  num_images_per_prompt: int = 1, eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
                  prompt_embeds=None, negative_prompt_embeds=None, pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None,
-                 output_type: str = "latent", return_dict: bool = True, cross_attention_kwargs=None,
+                 output_type: str = "pil", return_dict: bool = True, cross_attention_kwargs=None,
                  original_size=None, crops_coords_top_left=(0, 0), target_size=None,
                  controller=None, concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None,
                  region_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, lora_list: Optional[Sequence[str]] = None,
@@ -195,8 +195,16 @@ class LoraMultiConceptPipeline:
                 global_prompt, negative_prompt, [("style", 1.0)] if styleL else None, te_scale)
             region_prompt_embeds = []
             for lora_param, (rp, rn) in zip(lora_list, [(r[0], r[1]) for r in regions]):
-                combo = [(lora_param, 0.7), ("style", 0.5)] if styleL else [(lora_param, 1.0)]
-                pe, ne, pp, npp = self.encode_prompt(rp, rn, combo, te_scale)
+                if hasattr(concept_models, "encode_prompt"):      # the reference's literal sequence (lora_pipeline.py:337-343)
+                    if styleL:
+                        concept_models.set_adapters([lora_param, "style"], adapter_weights=[0.7, 0.5])
+                    else:
+                        concept_models.set_adapters(lora_param)
+                    pe, ne, pp, npp = concept_models.encode_prompt(prompt=rp, device=concept_models._execution_device, num_images_per_prompt=1,
+                                                                   do_classifier_free_guidance=True, negative_prompt=rn, lora_scale=te_scale)
+                else:
+                    combo = [(lora_param, 0.7), ("style", 0.5)] if styleL else [(lora_param, 1.0)]
+                    pe, ne, pp, npp = self.encode_prompt(rp, rn, combo, te_scale)
                 region_prompt_embeds.append((ne, pe, npp, pp))
         req = dict(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
                    pooled_prompt_embeds=pooled_prompt_embeds, negative_pooled_prompt_embeds=negative_pooled_prompt_embeds,
@@ -211,16 +219,29 @@ class LoraMultiConceptPipeline:
                                  controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0))[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
-        if output_type == "latent":
-            images = lat
-        else:
-            if self.vae_decode is None:
-                raise L.OmgHipError("no VAE attached: use output_type='latent' or construct the pipeline with "
-                                    "vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents")
-            images = self.vae_decode(lat)
+        images = self._postprocess(lat, output_type)
         if not return_dict:
             return (images,)
         return StableDiffusionXLPipelineOutput(images=images)
+
+    def _postprocess(self, lat: torch.Tensor, output_type: str):
+        """The reference's tail (lora_pipeline.py:635-661): VAE decode + ``image_processor.postprocess``.  ``"latent"``: the final
+        latents; ``"pt"``: decoded (n, 3, H, W) in [0, 1]; ``"np"``; ``"pil"`` (the reference's default): a list of PIL images."""
+        if output_type == "latent":
+            return lat
+        if output_type not in ("pil", "pt", "np"):
+            raise ValueError(f"output_type {output_type!r}")
+        if self.vae_decode is None:
+            raise L.OmgHipError("no VAE attached: use output_type='latent' or construct the pipeline with "
+                                "vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents")
+        images = self.vae_decode(lat)
+        if output_type == "pt":
+            return images
+        arr = images.detach().float().cpu().permute(0, 2, 3, 1).numpy()
+        if output_type == "np":
+            return arr
+        from PIL import Image
+        return [Image.fromarray(a) for a in (arr * 255).round().astype("uint8")]
 
     # ------------------------------------------------------------------ n independent requests in lock-step
     @torch.no_grad()
@@ -546,7 +567,7 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                  num_inference_steps: int = 50, guidance_scale: float = 5.0, generator=None, latents=None,
                  controlnet_conditioning_scale: float = 1.0, t2i_controlnet_conditioning_scale: float = 1.0, controller=None,
                  concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None, region_masks=None,
-                 region_prompt_embeds=None, region_image_embeds=None, output_type: str = "latent", return_dict: bool = True,
+                 region_prompt_embeds=None, region_image_embeds=None, output_type: str = "pil", return_dict: bool = True,
                  use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, **kwargs):
         if prompt_embeds is None:
             raise L.OmgHipError("pass prompt_embeds=/pooled_prompt_embeds= (text encoders are outside this package's scope)")
@@ -567,9 +588,5 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                                  controlnet_conditioning_scale=t2i_controlnet_conditioning_scale)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
-        if output_type != "latent":
-            if self.vae_decode is None:
-                raise L.OmgHipError("no VAE attached: use output_type='latent' or construct the pipeline with "
-                                    "vae_decode=omg_amd.vae.AutoencoderKLDecoder(...).decode_latents")
-            lat = self.vae_decode(lat)
+        lat = self._postprocess(lat, output_type)
         return StableDiffusionXLPipelineOutput(images=lat) if return_dict else (lat,)

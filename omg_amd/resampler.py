@@ -52,6 +52,10 @@ class Resampler(nn.Module):
         self._ff_packed = None
         return super().load_state_dict(*a, **k)
 
+    def _apply(self, fn, *a, **k):
+        self._ff_packed = None
+        return super()._apply(fn, *a, **k)
+
     def _pack(self):
         out = []
         for _, ff in self.layers:

@@ -91,6 +91,10 @@ class ClipTextEncoder(nn.Module):
     def device(self):
         return self.text_model.final_layer_norm.weight.device
 
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
     def load_state_dict(self, *a, **k):
         self._packed = None
         return super().load_state_dict(*a, **k)

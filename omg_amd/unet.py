@@ -331,6 +331,10 @@ class UNet2DConditionModel(nn.Module):
             if m is not self and hasattr(m, "invalidate_packed"):
                 m.invalidate_packed()
 
+    def _apply(self, fn, *a, **k):
+        self._boundary = {}
+        return super()._apply(fn, *a, **k)
+
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.invalidate_packed()

@@ -157,6 +157,10 @@ class AutoencoderKLDecoder(nn.Module):
     def device(self):
         return self.post_quant_conv.weight.device
 
+    def _apply(self, fn, *a, **k):
+        self._packed = {}
+        return super()._apply(fn, *a, **k)
+
     def load_state_dict(self, *a, **k):
         self._packed = {}
         return super().load_state_dict(*a, **k)

@@ -1,0 +1,75 @@
+"""B3 (CPU half): the diffusers-shaped constructors of omg_amd.compat on a synthetic model directory — what from_pretrained /
+load_lora_weights / tokenizer / .to() give the reference's build_model_sd (inference_lora.py:152-171).  Compute needs the GPU."""
+import os
+
+import pytest
+import torch
+
+from tests import _fake_hub as hub
+
+
+@pytest.fixture(scope="module")
+def dirs(tmp_path_factory):
+    root = tmp_path_factory.mktemp("hub")
+    return hub.write_sdxl_dir(str(root / "sdxl")), hub.write_controlnet_dir(str(root / "controlnet")), str(root)
+
+
+def test_from_pretrained_shapes_the_reference_objects(dirs):
+    from omg_amd import compat
+    from omg_amd._lib import OmgHipError
+    model, cn_dir, root = dirs
+    compat.clear_component_cache()
+    controlnet = compat.ControlNetModel.from_pretrained(cn_dir, torch_dtype=torch.float16).to("cpu")
+    pipe = compat.LoraMultiConceptPipeline.from_pretrained(model, controlnet=controlnet, torch_dtype=torch.float16, variant="fp16").to("cpu")
+    concept = compat.StableDiffusionXLPipeline.from_pretrained(model, torch_dtype=torch.float16, variant="fp16").to("cpu")
+    concept.enable_xformers_memory_efficient_attention()
+    assert concept._unet is pipe.unet and concept.vae is pipe.vae, "one set of weights serves both pipelines"
+    assert pipe.controlnet is controlnet and pipe.unet.dtype == torch.float16
+    assert type(pipe.scheduler).__name__ == "EulerDiscreteScheduler"            # what the checkpoint ships; the scripts never set one
+    # the tokenizer calls of inference_lora.py:276-283
+    ids = pipe.tokenizer("a man and a woman walking on the street")["input_ids"]
+    assert pipe.tokenizer("man")["input_ids"][1] in ids[1:-1] and pipe.tokenizer("dog")["input_ids"][1] not in ids[1:-1]
+    # LoRA files: kohya-ss SDXL keys for the concepts (as the reference's shipped files), PEFT keys for the style
+    p1 = hub.write_lora_file(os.path.join(root, "loras", "chris-evans.safetensors"), pipe.unet, 11, text_encoders=[pipe.text_encoder, pipe.text_encoder_2])
+    p2 = hub.write_lora_file(os.path.join(root, "style", "pytorch_lora_weights.safetensors"), pipe.unet, 12, style="peft", text_encoders=[pipe.text_encoder])
+    name = p1.split("/")[-1].split(".")[0]
+    concept.load_lora_weights(p1, weight_name="pytorch_lora_weights.safetensors", adapter_name=name)
+    pipe.load_lora_weights(os.path.dirname(p2), weight_name="pytorch_lora_weights.safetensors", adapter_name="style")
+    concept.load_lora_weights(os.path.dirname(p2), weight_name="pytorch_lora_weights.safetensors", adapter_name="style")
+    bank = concept.bank
+    assert set(bank.adapters) == {"chris-evans", "style"} and bank is pipe._comp.bank
+    assert set(bank.adapters["chris-evans"].text_encoder) == {1, 2} and set(bank.adapters["style"].text_encoder) == {1}
+    assert not bank.adapters["chris-evans"].skipped_keys
+    concept.set_adapters([name, "style"], adapter_weights=[0.7, 0.5])
+    assert concept._active == ((name, 0.7), ("style", 0.5))
+    # the controller is built from pipe.tokenizer exactly as the script does
+    from omg_amd.controller import AttentionReplace
+    from omg_amd.pipeline import revise_regionally_controlnet_forward
+    P = "a man and a woman walking on the street"
+    ctl = AttentionReplace([P, P], 50, cross_replace_steps={"default_": 1.0}, self_replace_steps=0.4, tokenizer=pipe.tokenizer, device="cpu",
+                           dtype=torch.float16, width=4, height=4)
+    revise_regionally_controlnet_forward(pipe.unet, ctl)
+    assert ctl.is_pure_replacement and ctl.num_att_layers == 2 * 17
+    with pytest.raises(OmgHipError):                               # no CPU fallback: the call itself needs the MI355X
+        pipe(prompt=[[P, P], [("a man", "", ), ("a woman", "")]], negative_prompt=["", ""], concept_models=concept, controller=ctl, stage=1,
+             lora_list=[name, name], styleL=False, num_inference_steps=2, image=None)
+
+
+def test_instantid_container_surface(dirs):
+    from omg_amd import compat
+    model, cn_dir, root = dirs
+    compat.clear_component_cache()
+    c = compat.StableDiffusionXLInstantIDPipeline.from_pretrained(model, torch_dtype=torch.float16, variant="fp16")
+    for m in ("load_ip_adapter_instantid", "set_image_proj_model", "set_ip_adapter", "set_ip_adapter_scale", "_encode_prompt_image_emb", "unet", "set_adapters"):
+        assert hasattr(c, m)
+    # get_face_embedding keeps the reference's selection rule (first of the ascending sort by (x1 - x0) * y1 - y0)
+    from PIL import Image
+    img = os.path.join(root, "face.png")
+    Image.new("RGB", (8, 8), (10, 20, 30)).save(img)
+
+    class FakeApp:
+        def get(self, bgr):
+            assert bgr.shape == (8, 8, 3) and tuple(bgr[0, 0]) == (30, 20, 10)      # BGR, as cv2.cvtColor(..., COLOR_RGB2BGR) gives
+            return [{"bbox": [0, 0, 4, 4], "embedding": "big"}, {"bbox": [0, 0, 1, 1], "embedding": "small"}]
+
+    assert compat.get_face_embedding(FakeApp(), [img]) == ["small"]

@@ -86,7 +86,7 @@ def test_two_stage_loop_matches_oracle(dev, sched, lora_mode):
     for stage in (1, 2):
         pctl.reset()
         traj = []
-        out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp,
+        out = pipe(output_type="latent", prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp,
                    height=H, width=W, num_inference_steps=S, guidance_scale=gs, latents=lat0,
                    cross_attention_kwargs={"scale": 0.8}, controller=pctl, concept_models=concept, stage=stage,
                    region_masks=masks, lora_list=["c0", "c1", "c2"], styleL=False, region_prompt_embeds=regions,
@@ -133,7 +133,7 @@ def test_graph_replay_is_bitwise_equal_to_eager(dev):
         lat0 = torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(seed))
         pctl.reset()
         traj = []
-        pipe(prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
+        pipe(output_type="latent", prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
              negative_pooled_prompt_embeds=np1.repeat(2, 1), height=H, width=W, num_inference_steps=S, guidance_scale=gs, latents=lat0,
              cross_attention_kwargs={"scale": 0.8}, controller=pctl, concept_models=concept, stage=2, region_masks=[m1, m2],
              lora_list=["c0", "c1"], styleL=False, region_prompt_embeds=regions, trajectory=traj, fusion_start=fstart, use_graph=use_graph)
@@ -242,7 +242,7 @@ def test_style_lora_runs_on_the_main_pass_too(dev, lora_mode):
     outs = {}
     for stage in (1, 2):
         pctl.reset()
-        out = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp,
+        out = pipe(output_type="latent", prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp,
                    height=H, width=W, num_inference_steps=S, guidance_scale=gs, latents=lat0, cross_attention_kwargs={"scale": 0.8},
                    controller=pctl, concept_models=concept, stage=stage, region_masks=masks, lora_list=["c0", "c1"], styleL=True,
                    region_prompt_embeds=regions, fusion_start=fstart, lora_mode=lora_mode).images.float().cpu()
@@ -280,7 +280,7 @@ def test_stale_graphs_are_dropped_when_the_bank_is_rebuilt(dev):
             re_, rp_ = embeds(cfg, 2, 13 + c, dtype)
             regions.append((re_[0:1], re_[1:2], rp_[0:1], rp_[1:2]))
         pctl.reset()
-        return pipe(prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
+        return pipe(output_type="latent", prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
                     negative_pooled_prompt_embeds=np1.repeat(2, 1), height=H, width=W, num_inference_steps=S, guidance_scale=gs,
                     latents=torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(5)), cross_attention_kwargs={"scale": scale},
                     controller=pctl, concept_models=concept, stage=2, region_masks=masks, lora_list=["c0", "c1"], styleL=False,
@@ -347,7 +347,7 @@ def test_fifty_step_trajectory_error_growth(dev, dtype):
     ref = opipe.denoise(main, [conc(0), conc(1)], osch, lat0 * osch.init_noise_sigma, S, gs, 2, masks=masks, fusion_start=fstart, record=rec)
     pctl.reset()
     traj = []
-    pipe(prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp, height=H, width=W,
+    pipe(output_type="latent", prompt_embeds=pe, negative_prompt_embeds=ne, pooled_prompt_embeds=pp, negative_pooled_prompt_embeds=npp, height=H, width=W,
          num_inference_steps=S, guidance_scale=gs, latents=lat0, cross_attention_kwargs={"scale": 0.8}, controller=pctl,
          concept_models=concept, stage=2, region_masks=masks, lora_list=["c0", "c1"], styleL=False, region_prompt_embeds=regions,
          trajectory=traj, fusion_start=fstart)
