@@ -176,7 +176,7 @@ typedef struct {
   int32_t B, heads, Nq, Nkv;  /* head_dim is 64                                       */
   const void* Q; int64_t ldq; int64_t q_bstride;   /* row stride / batch stride (elements) */
   const void* K; int64_t ldk; int64_t k_bstride;
-  const void* Vt;             /* [B, heads, 64, Nkv_pad] keys contiguous, zero padded  */
+  const void* Vt;             /* [B, heads, 64, Nkv_pad] from omg_transpose_v (its key order) */
   int32_t Nkv_pad;            /* % 64 == 0                                            */
   const int32_t* qk_src;      /* device [B]: batch index supplying Q,K; NULL = identity */
   float scale;
@@ -187,9 +187,11 @@ typedef struct {
 
 int omg_attn_fwd(const omg_attn_args* a, void* stream);
 
-/* V[B, Nkv, (head, 64)] (row stride ldv) -> Vt[B, heads, 64, Nkv_pad], zero padded. */
+/* V[B, Nkv, (head, 64)] (row stride ldv) -> Vt[B, heads, 64, Nkv_pad], zero padded.  mfma_key_order = 1 (what omg_attn_fwd
+ * consumes): inside every group of 16 keys the order is [0-3, 8-11, 4-7, 12-15] — the operand order of the P·V MFMA, one
+ * 16-byte LDS read per lane; 0: natural key order (a plain batched transpose, used by the VAE / text-encoder attention). */
 int omg_transpose_v(int dtype, const void* V, int64_t ldv, int64_t v_bstride,
-                    int B, int heads, int Nkv, int Nkv_pad, void* Vt, void* stream);
+                    int B, int heads, int Nkv, int Nkv_pad, void* Vt, int mfma_key_order, void* stream);
 
 /* ------------------------------------------------------------------------
  * Normalisation.  GroupNorm (NHWC, fp32 statistics, deterministic two-stage

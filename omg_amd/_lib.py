@@ -88,7 +88,7 @@ SYMBOLS = {
     "omg_gemm_mx8": (c_i32, [C.POINTER(GemmMx8Args), c_vp]),
     "omg_conv2d": (c_i32, [C.POINTER(Conv2dArgs), c_vp]),
     "omg_attn_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
-    "omg_transpose_v": (c_i32, [c_i32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "omg_transpose_v": (c_i32, [c_i32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "omg_groupnorm_ws_floats": (c_i64, [c_i32, c_i32, c_i32]),
     "omg_groupnorm": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "omg_layernorm": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -110,6 +110,7 @@ SYMBOLS = {
     "omg_debug_set_gemm_variant": (None, [c_i32]),
     "omg_debug_choose_variant": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "omg_debug_set_mx8_split": (None, [c_i32]),
+    "omg_debug_set_attn_variant": (None, [c_i32]),
 }
 
 _lib = None

@@ -15,7 +15,10 @@
 // V^T operand's LDS read (two 8-byte reads) — no cross-lane shuffles of P at all.
 //
 // V is consumed K-major (V^T[d][key]); omg_transpose_v produces that image once per
-// layer (HBM-bound, ~4 % of the layer's attention time at 64x64 tokens).
+// layer (HBM-bound, ~4 % of the layer's attention time at 64x64 tokens), with the keys of every 16-key group stored in the
+// order [0-3, 8-11 | 4-7, 12-15] so that a lane's operand is one ds_read_b128.  Both LDS tiles use rows of 128 B with
+// chunk ^= (row >> 1) & 7: any 16 rows distinct mod 16 then cover the 16 slots of the 256-byte bank row exactly once
+// (conflict-free ds_read_b128; the first version XOR-ed row & 7 and read V in 8-byte pieces: 2-way / 4-way conflicts).
 #include "common.h"
 
 namespace {
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
       const int row = ps * 32 + srow;
-      const int off = row * 128 + ((schunk ^ (row & 7)) << 4);
+      const int off = row * 128 + ((schunk ^ ((row >> 1) & 7)) << 4);
       *(u32x4*)(smem + buf * TILE + off) = hk[ps];
       *(u32x4*)(smem + (2 + buf) * TILE + off) = hv[ps];
     }
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = i * 32 + l31;
-        V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ (row & 7)) << 4));
+        V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
         s[i] = Vec<T>::mfma32(kf, qf[ks], s[i]);
       }
     }
@@ -158,14 +161,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
     for (int i = 0; i < 2; ++i)        // 32-key tile
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) { // 16-key k-step
-        const int c0 = i * 4 + k2 * 2;  // 16-B chunk holding keys [base+4hi .. +3]; chunk+1 holds base+8+4hi
+        const int c0 = i * 4 + k2 * 2 + hi;  // omg_transpose_v stores each 16-key group as [keys 0-3, 8-11 | 4-7, 12-15]: chunk c0 is this lane half's 8 keys
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const int row = dt * 32 + l31;
-          const char* rp = vt + row * 128 + hi * 8;
-          V4 lo = *(const V4*)(rp + ((c0 ^ (row & 7)) << 4));
-          V4 hi4 = *(const V4*)(rp + (((c0 + 1) ^ (row & 7)) << 4));
-          V8 vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+          const V8 vf = *(const V8*)(vt + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
           o[dt] = Vec<T>::mfma32(vf, pf[i][k2], o[dt]);
         }
       }
@@ -199,9 +199,386 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2: the same tiling with the softmax's VALU work roughly halved (at head_dim 64 the 16 MFMAs of a 64-key tile are 512 cycles
+// per wave while the v1 softmax issued ~240 VALU instructions, ~1100 cycles: the kernel was VALU-bound at 0.25 of the MFMA peak).
+//   * Q is pre-multiplied by scale * log2(e) once, and the score accumulators START at -m (the row's reference maximum) instead
+//     of zero: the MFMA chain delivers S' = (K Q'^T) - m directly and P = exp2(S') needs no per-element multiply-subtract.  The
+//     16-register tuple of -m is only rewritten when m moves.
+//   * m is a REFERENCE maximum, not the running maximum: it is raised (and O, l rescaled, S' shifted) only when some row of the
+//     wave sees a score more than ATTN_THR above it (wave-uniform branch; P <= 2^ATTN_THR = 256 stays far inside fp16 / bf16 range,
+//     l and O accumulate in fp32).  The first tile always takes the branch, so m >= the first tile's maximum and later, smaller
+//     tiles behave exactly as in the running-maximum scheme.  Order at a raise: O *= a, l *= a, S' -= d — every quantity still
+//     at the old reference is rescaled exactly once BEFORE this tile's P is exponentiated (cdna guide T13).
+//   * P is converted pairwise (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even).
+constexpr float ATTN_THR = 8.0f;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel2(AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], Vt[2]
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bq = p.qk_src ? p.qk_src[b] : b;
+  const int q0 = blockIdx.x * QB + w * 32;
+  int q = q0 + l31;
+  const bool qvalid = q < p.Nq;
+  if (!qvalid) q = p.Nq - 1;
+
+  V8 qf[4];
+  {
+    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const V8 raw = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ks][e] = (T)((float)raw[e] * p.scale_log2e);
+    }
+  }
+
+  const int srow = tid >> 3, schunk = tid & 7;
+  const char* kbase = p.K + ((long)bq * p.k_bs + h * 64) * 2;
+  const char* vbase = p.Vt + ((long)(b * p.heads + h) * 64) * (long)p.Nkv_pad * 2;
+  u32x4 hk[2], hv[2];
+  auto load_tile = [&](int kv0) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = ps * 32 + srow;
+      const int key = kv0 + row;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      hk[ps] = (key < p.Nkv) ? *(const u32x4*)(kbase + ((long)key * p.ldk + schunk * 8) * 2) : z;
+      hv[ps] = *(const u32x4*)(vbase + ((long)row * p.Nkv_pad + kv0 + schunk * 8) * 2);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int row = ps * 32 + srow;
+      const int off = row * 128 + ((schunk ^ ((row >> 1) & 7)) << 4);
+      *(u32x4*)(smem + buf * TILE + off) = hk[ps];
+      *(u32x4*)(smem + (2 + buf) * TILE + off) = hv[ps];
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_ref = 0.f, l_run = 0.f;       // scores and m_ref are in log2 units (Q carries scale * log2 e)
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+
+  const int ntiles = (p.Nkv + KVB - 1) / KVB;
+  load_tile(0);
+  store_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const int kv0 = t * KVB;
+    __syncthreads();
+    if (t + 1 < ntiles) load_tile(kv0 + KVB);
+    const char* kt = smem + buf * TILE;
+    const char* vt = smem + (2 + buf) * TILE;
+
+    // ---- S' = K · Q'^T - m_ref
+    f32x16 s[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 32 + l31;
+      s[i] = Vec<T>::mfma32(*(const V8*)(kt + row * 128 + ((hi ^ ((row >> 1) & 7)) << 4)), qf[0], negm);
+    }
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+      const int kc = ks * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + l31;
+        V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+        s[i] = Vec<T>::mfma32(kf, qf[ks], s[i]);
+      }
+    }
+    if (kv0 + KVB > p.Nkv) {      // key tail (last tile only)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= p.Nkv) s[i][r] = -1e30f;
+        }
+    }
+    // ---- tile maximum relative to the reference (pairs of fmaxf fuse into v_max3_f32)
+    float mt = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[0][r]), r + 1 < 16 ? s[0][r + 1] : s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[1][r]), s[1][r + 1]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    if (t == 0 || __builtin_amdgcn_ballot_w64(mt > ATTN_THR) != 0) {
+      // raise (first tile: set) the reference: everything at the old reference is rescaled once, S' moves to the new one
+      const float d = t == 0 ? mt : fmaxf(mt, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-d);
+      m_ref += d;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[i][r] *= alpha; s[i][r] -= d; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+    }
+    float psum = 0.f;
+    V8 pf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float e0 = __builtin_amdgcn_exp2f(s[i][r]);
+        const float e1 = __builtin_amdgcn_exp2f(s[i][r + 1]);
+        psum += e0 + e1;
+        const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
+        pf[i][r >> 3][r & 7] = pk[0];
+        pf[i][r >> 3][(r & 7) + 1] = pk[1];
+      }
+    l_run += psum;
+
+    // ---- O^T += V^T · P^T
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int c0 = i * 4 + k2 * 2 + hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int row = dt * 32 + l31;
+          const V8 vf = *(const V8*)(vt + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
+          o[dt] = Vec<T>::mfma32(vf, pf[i][k2], o[dt]);
+        }
+      }
+    if (t + 1 < ntiles) store_tile(buf ^ 1);
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = p.out_scale / l_tot;
+  if (qvalid) {
+    char* op = p.O + ((long)b * p.o_bs + (long)q * p.ldo + h * 64) * 2;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * hi;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[dt][g * 4 + e] * inv;
+        V4* dst = (V4*)(op + d * 2);
+        if (p.accumulate) {
+          V4 old = *dst;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+        }
+        V4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (T)v[e];
+        *dst = out;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v3: v2's arithmetic with the LDS traffic per MFMA halved and no register staging.
+//   * a wave owns TWO 32-row query blocks (64 rows): every K / V^T fragment read from LDS feeds two MFMAs instead of one (v1 / v2
+//     read one ds_read_b128 per MFMA; with 8-12 waves per CU the LDS port was as busy as the matrix pipe), and the softmax VALU
+//     work of one query block can be scheduled under the MFMAs of the other;
+//   * 256 query rows per workgroup (4 waves), so a staged K / V^T tile serves twice as many rows;
+//   * tiles go global -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave instruction, swizzle applied to the per-lane SOURCE
+//     address): no staging registers, no ds_write instructions; the DMA of tile t+1 is issued right after the barrier that
+//     releases its buffer and lands under the compute of tile t.
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* attn_gbl_ptr_t;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
+  constexpr int QW = 2;                      // 32-row query blocks per wave
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], Vt[2]
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bq = p.qk_src ? p.qk_src[b] : b;
+  const int q0 = blockIdx.x * (4 * 32 * QW) + w * (32 * QW);
+
+  V8 qf[QW][4];
+  int qrow[QW];
+#pragma unroll
+  for (int qb = 0; qb < QW; ++qb) {
+    int q = q0 + qb * 32 + l31;
+    qrow[qb] = q;
+    if (q >= p.Nq) q = p.Nq - 1;
+    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const V8 raw = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)raw[e] * p.scale_log2e);
+    }
+  }
+
+  // ---- LDS-DMA staging: one instruction = 8 rows x 128 B; wave w moves row blocks w and w + 4 of the K tile and of the V^T tile
+  const int prow = lane >> 3, ppos = lane & 7;
+  const char* kbase = p.K + ((long)bq * p.k_bs + h * 64) * 2;
+  const char* vbase = p.Vt + ((long)(b * p.heads + h) * 64) * (long)p.Nkv_pad * 2;
+  int srow[2], schunk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    srow[j] = (w + 4 * j) * 8 + prow;
+    schunk[j] = (ppos ^ ((srow[j] >> 1) & 7)) * 16;
+  }
+  auto dma_tile = [&](int kv0, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int key = kv0 + srow[j];
+      if (key > p.Nkv - 1) key = p.Nkv - 1;          // rows past the end repeat the last key; their scores are masked below
+      const char* ks_ = kbase + (long)key * p.ldk * 2 + schunk[j];
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)ks_, (attn_lds_ptr_t)(smem + buf * TILE + (w + 4 * j) * 1024), 16, 0, 0);
+      const char* vs_ = vbase + ((long)srow[j] * p.Nkv_pad + kv0) * 2 + schunk[j];
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)vs_, (attn_lds_ptr_t)(smem + (2 + buf) * TILE + (w + 4 * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 o[QW][2], negm[QW];
+  float m_ref[QW], l_run[QW];
+#pragma unroll
+  for (int qb = 0; qb < QW; ++qb) {
+    m_ref[qb] = 0.f; l_run[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; negm[qb][r] = 0.f; }
+  }
+
+  const int ntiles = (p.Nkv + KVB - 1) / KVB;
+  dma_tile(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const int kv0 = t * KVB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile t has landed
+    __syncthreads();                                     // ... everybody's has, and nobody reads buffer buf^1 any more
+    if (t + 1 < ntiles) dma_tile(kv0 + KVB, buf ^ 1);
+    const char* kt = smem + buf * TILE;
+    const char* vt = smem + (2 + buf) * TILE;
+
+    // ---- S' = K · Q'^T - m_ref for both query blocks: each K fragment feeds two MFMAs
+    f32x16 s[QW][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kc = ks * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + l31;
+        const V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) s[qb][i] = Vec<T>::mfma32(kf, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][i]);
+      }
+    }
+    V8 pf[QW][2][2];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+      if (kv0 + KVB > p.Nkv) {      // key tail (last tile only)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= p.Nkv) s[qb][i][r] = -1e30f;
+          }
+      }
+      float mt = s[qb][0][0];
+#pragma unroll
+      for (int r = 1; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][0][r]), r + 1 < 16 ? s[qb][0][r + 1] : s[qb][0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][1][r]), s[qb][1][r + 1]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      if (t == 0 || __builtin_amdgcn_ballot_w64(mt > ATTN_THR) != 0) {
+        const float d = t == 0 ? mt : fmaxf(mt, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m_ref[qb] += d;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o[qb][i][r] *= alpha; s[qb][i][r] -= d; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qb][r] = -m_ref[qb];
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(s[qb][i][r]);
+          const float e1 = __builtin_amdgcn_exp2f(s[qb][i][r + 1]);
+          psum += e0 + e1;
+          const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
+          pf[qb][i][r >> 3][r & 7] = pk[0];
+          pf[qb][i][r >> 3][(r & 7) + 1] = pk[1];
+        }
+      l_run[qb] += psum;
+    }
+
+    // ---- O^T += V^T · P^T: each V^T fragment feeds two MFMAs
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int c0 = i * 4 + k2 * 2 + hi;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int row = dt * 32 + l31;
+          const V8 vf = *(const V8*)(vt + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+          for (int qb = 0; qb < QW; ++qb) o[qb][dt] = Vec<T>::mfma32(vf, pf[qb][i][k2], o[qb][dt]);
+        }
+      }
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QW; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float inv = p.out_scale / l_tot;
+    if (qrow[qb] < p.Nq) {
+      char* op = p.O + ((long)b * p.o_bs + (long)qrow[qb] * p.ldo + h * 64) * 2;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * hi;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = o[qb][dt][g * 4 + e] * inv;
+          V4* dst = (V4*)(op + d * 2);
+          if (p.accumulate) {
+            V4 old = *dst;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+          }
+          V4 out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[e] = (T)v[e];
+          *dst = out;
+        }
+    }
+  }
+}
+
 // V[B, Nkv, heads*64] -> Vt[B, heads, 64, Nkv_pad]; grid (Nkv_pad/64, heads, B)
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_v_kernel(const char* V, long ldv, long v_bs, int heads, int Nkv, int Nkv_pad, char* Vt) {
+__global__ __launch_bounds__(256) void transpose_v_kernel(const char* V, long ldv, long v_bs, int heads, int Nkv, int Nkv_pad, char* Vt, int mfma_order) {
   __shared__ T tile[64][66];
   const int tid = threadIdx.x;
   const int kv0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -223,9 +600,13 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const char* V, long ld
 #pragma unroll
   for (int ps = 0; ps < 2; ++ps) {
     const int d = ps * 32 + (tid >> 3), c = tid & 7;
+    // key order inside each group of 16: [0-3, 8-11 | 4-7, 12-15] — the 8 keys one lane half of the P·V MFMA consumes per k-step
+    // (its P registers hold keys 4 hi + {0..3} and 8 + 4 hi + {0..3}) are then ONE 16-byte chunk of the row
     float f[8];
+    const int kb = mfma_order ? (c >> 1) * 16 + (c & 1) * 4 : c * 8;
+    const int kstep = mfma_order ? 8 : 4;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (float)tile[c * 8 + e][d];
+    for (int e = 0; e < 8; ++e) f[e] = (float)tile[kb + (e & 3) + (e >> 2) * kstep][d];
     *(u32x4*)(Vt + (((long)(b * heads + h) * 64 + d) * Nkv_pad + kv0 + c * 8) * 2) = pack8<T>(f);
   }
 }
@@ -322,7 +703,11 @@ AttnP make_params(const omg_attn_args* a) {
   return p;
 }
 
+int g_attn_variant = 0;      // 0 = heuristic (v3 / v2 by key count), 3 = v3 (64 query rows per wave, LDS-DMA staging), 2 = v2, 1 = v1; tools / A-B tests only
+
 }  // namespace
+
+extern "C" void omg_debug_set_attn_variant(int v) { g_attn_variant = v; }
 
 extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_attn_fwd: null args");
@@ -334,19 +719,28 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   AttnP p = make_params(a);
   dim3 grid((a->Nq + QB - 1) / QB, a->heads, a->B);
   hipStream_t s = (hipStream_t)stream;
-  if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel<f16>, grid, dim3(256), 0, s, p);
-  else OMG_LAUNCH(attn_fwd_kernel<bf16>, grid, dim3(256), 0, s, p);
+  if (g_attn_variant == 1) {
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel<f16>, grid, dim3(256), 0, s, p);
+    else OMG_LAUNCH(attn_fwd_kernel<bf16>, grid, dim3(256), 0, s, p);
+  } else if (g_attn_variant == 3 || (g_attn_variant == 0 && a->Nkv > 128)) {   // heuristic: v3 for self-attention, v2 for the 77 / 93 / 16-key cross calls (one or two tiles: latency-bound, v3's 256-row blocks only add to it)
+    dim3 grid3((a->Nq + 255) / 256, a->heads, a->B);
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel3<f16>, grid3, dim3(256), 0, s, p);
+    else OMG_LAUNCH(attn_fwd_kernel3<bf16>, grid3, dim3(256), 0, s, p);
+  } else {
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel2<f16>, grid, dim3(256), 0, s, p);
+    else OMG_LAUNCH(attn_fwd_kernel2<bf16>, grid, dim3(256), 0, s, p);
+  }
   return omg_check_launch("attn_fwd");
 }
 
 extern "C" int omg_transpose_v(int dtype, const void* V, int64_t ldv, int64_t v_bstride, int B, int heads, int Nkv,
-                               int Nkv_pad, void* Vt, void* stream) {
+                               int Nkv_pad, void* Vt, int mfma_key_order, void* stream) {
   OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_transpose_v: dtype");
   OMG_REQUIRE(V && Vt && Nkv_pad % 64 == 0 && Nkv_pad >= Nkv && ldv % 8 == 0, "omg_transpose_v: args");
   dim3 grid(Nkv_pad / 64, heads, B);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == OMG_F16) OMG_LAUNCH(transpose_v_kernel<f16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt);
-  else OMG_LAUNCH(transpose_v_kernel<bf16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt);
+  if (dtype == OMG_F16) OMG_LAUNCH(transpose_v_kernel<f16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt, mfma_key_order);
+  else OMG_LAUNCH(transpose_v_kernel<bf16>, grid, dim3(256), 0, s, (const char*)V, (long)ldv, (long)v_bstride, heads, Nkv, Nkv_pad, (char*)Vt, mfma_key_order);
   return omg_check_launch("transpose_v");
 }
 

@@ -275,8 +275,10 @@ def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, up
     return y
 
 
-def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``v``: (B, Nkv, >=heads*64) view with unit inner stride -> Vt (B, heads, 64, Nkv_pad)."""
+def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                mfma_order: bool = True) -> torch.Tensor:
+    """``v``: (B, Nkv, >=heads*64) view with unit inner stride -> Vt (B, heads, 64, Nkv_pad).  ``mfma_order`` (default): the key
+    order :func:`attention` consumes ([0-3, 8-11, 4-7, 12-15] inside every 16 keys); False: a plain transpose."""
     _dev(v)
     B, Nkv = v.shape[0], v.shape[1]
     if nkv_pad is None:
@@ -284,7 +286,7 @@ def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None, out:
     vt = out if out is not None else torch.empty((B, heads, 64, nkv_pad), dtype=v.dtype, device=v.device)
     assert vt.is_contiguous() and tuple(vt.shape) == (B, heads, 64, nkv_pad)
     L.check(L.lib().omg_transpose_v(_dt(v), v.data_ptr(), v.stride(1), v.stride(0), B, heads, Nkv, nkv_pad,
-                                    vt.data_ptr(), _stream()), "omg_transpose_v")
+                                    vt.data_ptr(), int(mfma_order), _stream()), "omg_transpose_v")
     return vt
 
 

@@ -177,7 +177,7 @@ class ClipTextEncoder(nn.Module):
                 penultimate = x                                     # hidden_states[-2] = the input of the last layer
             h = lyr.layer_norm1(x)
             qkv = ops.gemm(h, w["wqkv"], bias=w["bqkv"]).view(B, T, 3 * d)
-            vt = ops.transpose_v(qkv[:, :, 2 * d:], heads)          # (B, heads, 64, 128)
+            vt = ops.transpose_v(qkv[:, :, 2 * d:], heads, mfma_order=False)   # (B, heads, 64, 128), plain transpose
             attn = torch.empty(B * T, d, dtype=x.dtype, device=x.device)
             for b in range(B):
                 for hh in range(heads):

@@ -87,7 +87,7 @@ class _MidAttention(nn.Module):
                          torch.cat([self.to_q.bias.data, self.to_k.bias.data, self.to_v.bias.data]).contiguous())
         h = self.group_norm(x).reshape(B * HW, C)
         qkv = ops.gemm(h, self._qkv[0], bias=self._qkv[1]).view(B, HW, 3 * C)
-        vt = ops.transpose_v(qkv[:, :, 2 * C:], C // 64)                       # (B, C/64, 64, HW_pad) == V^T [C][HW_pad]
+        vt = ops.transpose_v(qkv[:, :, 2 * C:], C // 64, mfma_order=False)     # (B, C/64, 64, HW_pad) == V^T [C][HW_pad]
         attn = torch.empty((B * HW, C), dtype=x.dtype, device=x.device)
         scores = torch.empty((HW, HW), dtype=x.dtype, device=x.device)
         for b in range(B):

@@ -316,3 +316,18 @@ def test_gemm_variants_are_bitwise_identical(dev, dtype):
                 assert torch.equal(o, r), f"variant {v} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
     finally:
         lib.omg_debug_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Nkv", [77, 128, 1000])
+def test_transpose_v_both_key_orders(dev, dtype, Nkv):
+    """omg_transpose_v: plain transpose (VAE / text-encoder attention as GEMMs) and the P·V-MFMA key order omg_attn_fwd consumes:
+    inside every group of 16 keys [0-3, 8-11, 4-7, 12-15]; padding keys are zero."""
+    B, heads = 2, 3
+    v = rnd(B, Nkv, heads * 64, dtype=dtype, dev=dev, seed=9)
+    pad = (Nkv + 63) // 64 * 64
+    ref = torch.zeros(B, heads, 64, pad, dtype=dtype)
+    ref[..., :Nkv] = v.cpu().reshape(B, Nkv, heads, 64).permute(0, 2, 3, 1)
+    assert torch.equal(ops.transpose_v(v, heads, mfma_order=False).cpu(), ref)
+    idx = torch.arange(pad).reshape(-1, 16)[:, [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15]].reshape(-1)
+    assert torch.equal(ops.transpose_v(v, heads).cpu(), ref[..., idx])

@@ -1,0 +1,39 @@
+"""Flash-attention kernel variants on the benchmark's shapes (GPU box).  python tools/attn_bench.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from omg_amd import ops, _lib as L
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+dev, dt = torch.device("cuda:0"), torch.float16
+lib = L.lib()
+print("# (B, heads, Nq, Nkv): TF/s of v1 (running max) | v2 (reference max) | v3 (64 rows per wave, LDS-DMA); max |v3 - v1|")
+for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20, 1024, 77), (64, 10, 4096, 77), (32, 10, 4096, 4096), (64, 20, 1024, 16)]:
+    C = heads * 64
+    q = torch.randn(B, Nq, C, device=dev, dtype=dt)
+    k = torch.randn(B, Nkv, C, device=dev, dtype=dt) * 1.5
+    v = torch.randn(B, Nkv, C, device=dev, dtype=dt)
+    vt = ops.transpose_v(v, heads)
+    out = torch.empty(B, Nq, C, device=dev, dtype=dt)
+    fl = 4.0 * B * heads * Nq * Nkv * 64
+    res, outs = [], []
+    for var in (1, 2, 3):
+        lib.omg_debug_set_attn_variant(var)
+        ms = timeit(lambda: ops.attention(q, k, vt, heads, 0.125, out=out))
+        res.append(fl / ms / 1e9)
+        outs.append(out.clone())
+    lib.omg_debug_set_attn_variant(0)
+    print(f"({B},{heads},{Nq},{Nkv}): {res[0]:7.0f} | {res[1]:7.0f} | {res[2]:7.0f}   max |d| {(outs[0].float() - outs[2].float()).abs().max().item():.2e}")
