@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--images-per-step", type=int, default=8, help="independent requests run in lock-step per step (one batched UNet forward)")
     ap.add_argument("--by-shape", default="", help="also write the roofline leg's per-shape table (ms per bench step, TF/s) to this file")
     ap.add_argument("--no-vae", action="store_true", help="stop at the latents (skip the VAE decode that ends the reference's stage-2 call)")
+    ap.add_argument("--vae-16bit", action="store_true", help="decode in bf16 storage instead of the reference's fp32 up blocks (faster, NOT the reference's precision)")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
 
@@ -113,7 +114,10 @@ def main():
     vae = None
     if not args.no_vae:           # the tail of the reference's call: vae.decode(latents / scaling_factor) + postprocess (lora_pipeline.py:635-661)
         from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
-        vae = AutoencoderKLDecoder(VaeConfig.tiny() if args.tiny else VaeConfig.sdxl(), dtype=torch.bfloat16, device=dev).init_synthetic_(seed=1)
+        # as the reference decodes (upcast_vae, lora_pipeline.py:639-652): pipeline dtype for post_quant_conv / conv_in / mid block, fp32 up blocks;
+        # --vae-16bit: everything in bf16 storage (fp32 accumulate), the labelled faster option
+        vae = AutoencoderKLDecoder(VaeConfig.tiny() if args.tiny else VaeConfig.sdxl(), dtype=torch.bfloat16 if args.vae_16bit else dt, device=dev,
+                                   upcast=not args.vae_16bit).init_synthetic_(seed=1)
     masks = c2_masks(HW, HW, device=dev)
     n_steps = args.warmup + args.steps
     ips = args.images_per_step
@@ -163,7 +167,9 @@ def main():
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),
                       "global_batch": world * ips, "images_per_step_per_gpu": ips, "main_batch": 4 * ips, "concept_batch": 4 * ips, "accounting": "stage-2 only, as executed by the reference "
                       "(200 main + 136 concept sample-forwards = 2.273 PFLOP/image); no redundancy shortcuts",
-                      "vae_decode": "skipped (--no-vae)" if args.no_vae else "both 1024^2 images of every request decoded inside the timed region (bf16 storage, fp32 accumulate; +10.5 TFLOP per request, not counted in the FLOP accounting)",
+                      "vae_decode": "skipped (--no-vae)" if args.no_vae else ("both 1024^2 images of every request decoded inside the timed region, "
+                                     + ("bf16 storage / fp32 accumulate (--vae-16bit)" if args.vae_16bit else "as the reference's upcast decode: fp16 post_quant / conv_in / mid block, fp32 up blocks on the f32-input MFMA")
+                                     + "; +10.5 TFLOP per request, not counted in the FLOP accounting"),
                       "parallelism": f"dp{world}", "tiny_debug": bool(args.tiny),
                       "step_loop": "eager" if args.no_graph else "hipGraph replay (3 captured step regimes)", "lora": "merged weight slots, "
                       "main + concept samples of all requests batched per fused step (8 samples per request)"},
@@ -233,8 +239,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:          # orderly shutdown: the other ranks wait for rank 0's instrumented passes, then RCCL is torn down
-        parallel.barrier()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        parallel.barrier()     # orderly shutdown: the other ranks wait for rank 0's instrumented passes, then RCCL is torn down
         torch.distributed.destroy_process_group()
 
 

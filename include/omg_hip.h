@@ -215,6 +215,25 @@ int omg_layernorm_mx8(int dtype, const void* X, int64_t ldx, int M, int C, float
                       void* scales, int s_ld, void* stream);
 
 /* ------------------------------------------------------------------------
+ * fp32 path of the VAE decode.  The reference upcasts the VAE before decoding ("it overflows in float16", upcast_vae at
+ * src/pipelines/lora_pipeline.py:639-652); with torch 2's attention processor diffusers 0.25 then runs post_quant_conv, conv_in
+ * and the mid block in fp16 and the UP BLOCKS, conv_norm_out and conv_out in fp32.  omg_conv2d_f32: NHWC fp32 convolution
+ * (3x3 pad 1 or 1x1, stride 1, optional fused nearest-2x upsample of the input), fp32 weights [Cout][ky][kx][Cin], fp32 bias and
+ * residual, on the f32-input MFMA (exact fp32 products, fp32 accumulation).  omg_groupnorm / omg_conv_out accept
+ * dtype = OMG_F32 (fp32 storage, fp32 gamma / beta / weights); omg_cast_f32 is the decoder's `sample.to(upscale_dtype)`.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int32_t B, Hin, Win, Cin;   /* Cin % 32 == 0                                        */
+  int32_t Hout, Wout, Cout;   /* Hout = Hin * (upsample ? 2 : 1); Cout % 4 == 0       */
+  int32_t ksize, upsample;
+  const void* X; const void* W; const void* bias; const void* residual;   /* fp32; bias / residual may be NULL */
+  void* Y;                    /* [B, Hout, Wout, Cout] fp32                           */
+} omg_conv2d_f32_args;
+
+int omg_conv2d_f32(const omg_conv2d_f32_args* a, void* stream);
+int omg_cast_f32(int dtype, const void* X, float* Y, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------
  * Boundary convolutions (NCHW latents <-> NHWC features).
  * conv_in : UNet2DConditionModel.conv_in  (4 -> C0, 3x3), input NCHW fp32|T; executed as a 64-column
  *           im2col + the MFMA GEMM (K = 36 padded to one 64-wide slice).

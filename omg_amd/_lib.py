@@ -58,6 +58,14 @@ class Conv2dArgs(C.Structure):
     ]
 
 
+class Conv2dF32Args(C.Structure):
+    _fields_ = [
+        ("B", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32),
+        ("Hout", c_i32), ("Wout", c_i32), ("Cout", c_i32), ("ksize", c_i32), ("upsample", c_i32),
+        ("X", c_vp), ("W", c_vp), ("bias", c_vp), ("residual", c_vp), ("Y", c_vp),
+    ]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("dtype", c_i32), ("B", c_i32), ("heads", c_i32), ("Nq", c_i32), ("Nkv", c_i32),
@@ -87,6 +95,8 @@ SYMBOLS = {
     "omg_quant_mx8": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp]),
     "omg_gemm_mx8": (c_i32, [C.POINTER(GemmMx8Args), c_vp]),
     "omg_conv2d": (c_i32, [C.POINTER(Conv2dArgs), c_vp]),
+    "omg_conv2d_f32": (c_i32, [C.POINTER(Conv2dF32Args), c_vp]),
+    "omg_cast_f32": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp]),
     "omg_attn_fwd": (c_i32, [C.POINTER(AttnArgs), c_vp]),
     "omg_transpose_v": (c_i32, [c_i32, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "omg_groupnorm_ws_floats": (c_i64, [c_i32, c_i32, c_i32]),

@@ -103,10 +103,11 @@ class _Components:
         vcfg = VaeConfig(latent_channels=vc.get("latent_channels", 4), out_channels=vc.get("out_channels", 3),
                          block_out_channels=tuple(vc["block_out_channels"]), layers_per_block=vc.get("layers_per_block", 2),
                          norm_num_groups=vc.get("norm_num_groups", 32), scaling_factor=vc.get("scaling_factor", 0.13025))
-        # decode precision: see AutoencoderKLDecoder (16-bit storage / fp32 accumulate by default; bf16 is overflow-safe)
-        self.vae = AutoencoderKLDecoder(vcfg, dtype=torch.bfloat16, device=dev)
+        # `needs_upcasting = vae.dtype == float16 and vae.config.force_upcast` (lora_pipeline.py:641): the reference then decodes with
+        # fp32 up blocks; AutoencoderKLDecoder(upcast=True) is that decode
+        up = dtype == torch.float16 and bool(vc.get("force_upcast", True))
+        self.vae = AutoencoderKLDecoder(vcfg, dtype=dtype, device=dev, upcast=up)
         loaders.load_model_weights(self.vae, _weights_file(os.path.join(path, "vae"), "diffusion_pytorch_model", variant), allow_extra=True)
-        self.vae.force_upcast = bool(vc.get("force_upcast", True))
         self.text_encoder = self._text_encoder("text_encoder", with_projection=False)
         self.text_encoder_2 = self._text_encoder("text_encoder_2", with_projection=True)
         from transformers import CLIPTokenizer

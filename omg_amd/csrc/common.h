@@ -45,6 +45,19 @@ template <typename T> OMG_DEV u32x4 pack8(const float (&f)[8]) {
   return __builtin_bit_cast(u32x4, v);
 }
 
+// 8 consecutive elements <-> 8 floats for 16-bit storage (one 16-byte access) and for fp32 storage (two)
+template <typename T> OMG_DEV void load8(const char* p, float (&f)[8]) { unpack8<T>(*(const u32x4*)p, f); }
+template <> OMG_DEV void load8<float>(const char* p, float (&f)[8]) {
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 16);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+}
+template <typename T> OMG_DEV void store8(char* p, const float (&f)[8]) { *(u32x4*)p = pack8<T>(f); }
+template <> OMG_DEV void store8<float>(char* p, const float (&f)[8]) {
+  *(f32x4*)p = f32x4{f[0], f[1], f[2], f[3]};
+  *(f32x4*)(p + 16) = f32x4{f[4], f[5], f[6], f[7]};
+}
+
 OMG_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) — the IEEE division of silu_f is ten VALU instructions (GEMM epilogues)
 OMG_DEV float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

@@ -56,12 +56,12 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const char* X, int B, int
       const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
       if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
       float f[8];
-      unpack8<T>(*(const u32x4*)(X + ((((long)b * H + iy) * W + ix) * Cin + vec * 8) * 2), f);
+      load8<T>(X + ((((long)b * H + iy) * W + ix) * Cin + vec * 8) * (long)sizeof(T), f);
 #pragma unroll
       for (int co = 0; co < 8; ++co) {
         if (co < Cout) {
           float wv[8];
-          unpack8<T>(*(const u32x4*)(Wt + ((long)co * K + tap * Cin + vec * 8) * 2), wv);
+          load8<T>(Wt + ((long)co * K + tap * Cin + vec * 8) * (long)sizeof(T), wv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[co] += f[e] * wv[e];
         }
@@ -232,16 +232,38 @@ extern "C" int omg_conv_in(int dtype, const void* X, int x_is_f32, int B, int Ci
   return omg_gemm(&g, stream);
 }
 
+// 16-bit -> fp32 copy of a contiguous tensor (the VAE decoder's `sample.to(upscale_dtype)` between mid block and up blocks)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_f32_kernel(const char* X, float* Y, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    float f[8];
+    load8<T>(X + i * 16, f);
+    store8<float>((char*)(Y + i * 8), f);
+  }
+}
+
+extern "C" int omg_cast_f32(int dtype, const void* X, float* Y, int64_t n, void* stream) {
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_cast_f32: dtype");
+  OMG_REQUIRE(X && Y && n % 8 == 0, "omg_cast_f32: args");
+  if (n == 0) return OMG_OK;
+  long blocks = (n / 8 + 255) / 256; if (blocks > 16384) blocks = 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OMG_F16) OMG_LAUNCH(cast_f32_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const char*)X, Y, (long)(n / 8));
+  else OMG_LAUNCH(cast_f32_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, Y, (long)(n / 8));
+  return omg_check_launch("cast_f32");
+}
+
 extern "C" int omg_conv_out(int dtype, const void* X, int B, int H, int W, int Cin, const void* Wt, const void* bias,
                             int Cout, float* Y, void* stream) {
-  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_conv_out: dtype");
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16 || dtype == OMG_F32, "omg_conv_out: dtype");
   OMG_REQUIRE(X && Wt && Y && Cin % 8 == 0 && Cout >= 1 && Cout <= 8, "omg_conv_out: args");
   const long npix = (long)B * H * W;
   if (npix == 0) return OMG_OK;
   long blocks = (npix + 3) / 4; if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OMG_F16) OMG_LAUNCH(conv_out_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Cout, Y);
-  else OMG_LAUNCH(conv_out_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
+  else if (dtype == OMG_BF16) OMG_LAUNCH(conv_out_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
+  else OMG_LAUNCH(conv_out_kernel<float>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const float*)bias, Cout, Y);
   return omg_check_launch("conv_out");
 }
 

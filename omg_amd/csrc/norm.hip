@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_MAX_CHUNKS = 1024;    // partial-sum chunks per sample (64 until round 2: a 1024x1024x128 VAE map then ran on 128 workgroups)
 
 struct GnP {
   const char* X1; int C1; const char* X2; int C2;
@@ -23,9 +23,9 @@ struct GnP {
 template <typename T>
 OMG_DEV void gn_load(const GnP& p, int b, int pix, int vec, float (&f)[8]) {
   const int c = vec * 8;
-  const char* src = (c < p.C1) ? p.X1 + (((long)b * p.HW + pix) * p.C1 + c) * 2
-                               : p.X2 + (((long)b * p.HW + pix) * p.C2 + (c - p.C1)) * 2;
-  unpack8<T>(*(const u32x4*)src, f);
+  const char* src = (c < p.C1) ? p.X1 + (((long)b * p.HW + pix) * p.C1 + c) * (long)sizeof(T)
+                               : p.X2 + (((long)b * p.HW + pix) * p.C2 + (c - p.C1)) * (long)sizeof(T);
+  load8<T>(src, f);
 }
 
 template <typename T>
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
     const int vec = tv + v * p.tpp;
     if (v < p.vpt && vec < p.nvec) {
       float ga[8], be[8];
-      unpack8<T>(*(const u32x4*)(p.gamma + (long)vec * 16), ga);
-      unpack8<T>(*(const u32x4*)(p.beta + (long)vec * 16), be);
+      load8<T>(p.gamma + (long)vec * 8 * sizeof(T), ga);
+      load8<T>(p.beta + (long)vec * 8 * sizeof(T), be);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int g = (vec * 8 + e) / p.cpg;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
           if (p.silu) y = silu_f(y);
           f[e] = y;
         }
-        *(u32x4*)(p.Y + (((long)b * p.HW + pix) * C + vec * 8) * 2) = pack8<T>(f);
+        store8<T>(p.Y + (((long)b * p.HW + pix) * C + vec * 8) * (long)sizeof(T), f);
       }
     }
   }
@@ -290,7 +290,7 @@ extern "C" int64_t omg_groupnorm_ws_floats(int B, int groups, int HW) {
 extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
                              float eps, const void* gamma, const void* beta, int silu, float* workspace, void* Y,
                              void* stream) {
-  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_groupnorm: dtype");
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16 || dtype == OMG_F32, "omg_groupnorm: dtype");
   OMG_REQUIRE(X1 && gamma && beta && workspace && Y && (C2 == 0 || X2), "omg_groupnorm: null operand");
   const int C = C1 + C2;
   OMG_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && groups <= 64 && groups > 0, "omg_groupnorm: channels/groups");
@@ -318,9 +318,12 @@ extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, 
   if (dtype == OMG_F16) {
     OMG_LAUNCH(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
     OMG_LAUNCH(gn_apply_kernel<f16>, grid, dim3(256), 0, s, p);
-  } else {
+  } else if (dtype == OMG_BF16) {
     OMG_LAUNCH(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
     OMG_LAUNCH(gn_apply_kernel<bf16>, grid, dim3(256), 0, s, p);
+  } else {          // fp32 storage: the up-blocks of the upcast VAE decode (lora_pipeline.py:639-652)
+    OMG_LAUNCH(gn_stats_kernel<float>, grid, dim3(256), lds, s, p);
+    OMG_LAUNCH(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
   }
   return omg_check_launch("groupnorm");
 }

@@ -215,6 +215,10 @@ class Conv2d(_Packed):
 
     def forward(self, x: torch.Tensor, *, x2: Optional[torch.Tensor] = None, upsample: bool = False,
                 group_bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.weight.dtype == torch.float32:          # fp32 storage (the up blocks of the upcast VAE decode): f32-input MFMA kernel
+            if x2 is not None or group_bias is not None or self.stride != 1:
+                raise L.OmgHipError("the fp32 convolution supports stride 1 without concat / per-sample bias (all the VAE decoder needs)")
+            return ops.conv2d_f32(x, self.packed_weight(), self.ksize, upsample=upsample, bias=self.bias, residual=residual)
         return ops.conv2d(x, self.packed_weight(), self.ksize, stride=self.stride, upsample=upsample, x2=x2, bias=self.bias,
                           group_bias=group_bias, residual=residual)
 

@@ -18,7 +18,9 @@ from . import _lib as L
 _DT = {torch.float16: L.OMG_F16, torch.bfloat16: L.OMG_BF16}
 
 
-def _dt(t: torch.Tensor) -> int:
+def _dt(t: torch.Tensor, allow_f32: bool = False) -> int:
+    if allow_f32 and t.dtype == torch.float32:
+        return L.OMG_F32
     try:
         return _DT[t.dtype]
     except KeyError:
@@ -275,6 +277,44 @@ def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, up
     return y
 
 
+def conv2d_f32(x: torch.Tensor, w: torch.Tensor, ksize: int, *, upsample: bool = False, bias: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 NHWC convolution on the f32-input MFMA (omg_conv2d_f32): the up blocks of the upcast VAE decode.
+    ``w``: fp32 [Cout, ksize*ksize*Cin] (pack_conv_weight of the fp32 OIHW tensor)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    B, Hin, Win, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == ksize * ksize * Cin
+    Ho, Wo = (2 * Hin, 2 * Win) if upsample else (Hin, Win)
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    a = L.Conv2dF32Args()
+    a.B, a.Hin, a.Win, a.Cin, a.Hout, a.Wout, a.Cout, a.ksize, a.upsample = B, Hin, Win, Cin, Ho, Wo, Cout, ksize, int(upsample)
+    a.X, a.W, a.Y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        a.bias = bias.data_ptr()
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.shape == y.shape
+        a.residual = residual.data_ptr()
+    if _PROF is not None:
+        t0 = _PROF.begin()
+        L.check(L.lib().omg_conv2d_f32(C.byref(a), _stream()), "omg_conv2d_f32")
+        _PROF.end("gemm_f32", 2.0 * B * Ho * Wo * Cout * ksize * ksize * Cin, t0, ("conv_f32", B * Ho * Wo, Cout, ksize * ksize * Cin, 0, 1, 0))
+        return y
+    L.check(L.lib().omg_conv2d_f32(C.byref(a), _stream()), "omg_conv2d_f32")
+    return y
+
+
+def cast_f32(x: torch.Tensor) -> torch.Tensor:
+    """16-bit -> fp32 copy (same shape / layout)."""
+    _dev(x)
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    L.check(L.lib().omg_cast_f32(_dt(x), x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "omg_cast_f32")
+    return y
+
+
 def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None, out: Optional[torch.Tensor] = None,
                 mfma_order: bool = True) -> torch.Tensor:
     """``v``: (B, Nkv, >=heads*64) view with unit inner stride -> Vt (B, heads, 64, Nkv_pad).  ``mfma_order`` (default): the key
@@ -379,7 +419,8 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
         C2 = x2.shape[-1]
     y = torch.empty(x1.shape[:-1] + (C1 + C2,), dtype=x1.dtype, device=x1.device)
     ws = _gn_workspace(x1.device, B, groups, HW)
-    L.check(L.lib().omg_groupnorm(_dt(x1), x1.data_ptr(), C1, _p(x2), C2, B, HW, groups, eps, gamma.data_ptr(),
+    assert gamma.dtype == x1.dtype and beta.dtype == x1.dtype
+    L.check(L.lib().omg_groupnorm(_dt(x1, allow_f32=True), x1.data_ptr(), C1, _p(x2), C2, B, HW, groups, eps, gamma.data_ptr(),
                                   beta.data_ptr(), int(silu), ws.data_ptr(), y.data_ptr(), _stream()), "omg_groupnorm")
     return y
 
@@ -436,7 +477,8 @@ def conv_out(x_nhwc: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]
     if out is None:
         out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x_nhwc.device)
     assert out.is_contiguous() and out.dtype == torch.float32
-    L.check(L.lib().omg_conv_out(_dt(x_nhwc), x_nhwc.data_ptr(), B, H, W, Cin, w.data_ptr(), _p(bias), Cout,
+    assert w.dtype == x_nhwc.dtype and (bias is None or bias.dtype == x_nhwc.dtype)
+    L.check(L.lib().omg_conv_out(_dt(x_nhwc, allow_f32=True), x_nhwc.data_ptr(), B, H, W, Cin, w.data_ptr(), _p(bias), Cout,
                                  out.data_ptr(), _stream()), "omg_conv_out")
     return out
 

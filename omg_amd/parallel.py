@@ -21,7 +21,8 @@ def init_distributed(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("OMG_FORCE_DIST") == "1"      # torchrun with one process: still
+    if (world > 1 or launched) and not dist.is_initialized():                                    # bring RCCL up (world-size-1 smoke)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -42,7 +43,7 @@ def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
 def gather_latents(local: torch.Tensor, n_total: int, rank: int, world: int) -> torch.Tensor:
     """all_gather of per-rank latents ``(n_local, ...)`` into ``(n_total, ...)`` in global image order.
     Ragged shards are padded to the largest shard for the collective and trimmed afterwards."""
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local
     base, extra = divmod(n_total, world)
     n_max = base + (1 if extra else 0)

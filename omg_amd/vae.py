@@ -117,8 +117,9 @@ class _UpBlock(nn.Module):
 
 
 class _Decoder(nn.Module):
-    def __init__(self, cfg, dtype, device):
+    def __init__(self, cfg, dtype, device, up_dtype=None):
         super().__init__()
+        up_dtype = up_dtype or dtype
         rev = list(reversed(cfg.block_out_channels))
         top = rev[0]
         self.conv_in_w = None
@@ -128,25 +129,31 @@ class _Decoder(nn.Module):
         self.mid_block.attentions = nn.ModuleList([_MidAttention(top, cfg, dtype, device)])
         blocks, prev = [], top
         for i, c in enumerate(rev):
-            blocks.append(_UpBlock(prev, c, cfg.layers_per_block + 1, i != len(rev) - 1, cfg, dtype, device))
+            blocks.append(_UpBlock(prev, c, cfg.layers_per_block + 1, i != len(rev) - 1, cfg, up_dtype, device))
             prev = c
         self.up_blocks = nn.ModuleList(blocks)
-        self.conv_norm_out = GroupNorm(cfg.norm_num_groups, rev[-1], cfg.norm_eps, dtype=dtype, device=device)
-        self.conv_out = Conv2d(rev[-1], cfg.out_channels, 3, dtype=dtype, device=device)       # parameters only; run by ops.conv_out
+        self.conv_norm_out = GroupNorm(cfg.norm_num_groups, rev[-1], cfg.norm_eps, dtype=up_dtype, device=device)
+        self.conv_out = Conv2d(rev[-1], cfg.out_channels, 3, dtype=up_dtype, device=device)    # parameters only; run by ops.conv_out
 
 
 class AutoencoderKLDecoder(nn.Module):
     """``decode(z)`` of diffusers' AutoencoderKL (decoder half + post_quant_conv)."""
 
-    def __init__(self, cfg: Optional[VaeConfig] = None, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, cfg: Optional[VaeConfig] = None, dtype=torch.bfloat16, device="cuda", upcast: bool = False):
+        """``upcast=True`` reproduces the reference's ``upcast_vae()`` decode (lora_pipeline.py:639-652; diffusers 0.25 with torch 2's
+        attention processor [recalled]): post_quant_conv, conv_in and the mid block stay in ``dtype`` (the pipeline's fp16), the
+        sample is cast to fp32 after the mid block and the up blocks, conv_norm_out and conv_out run in fp32 (fp32 weights, fp32
+        activations, f32-input MFMA).  ``upcast=False``: everything in ``dtype`` (16-bit storage, fp32 accumulation) — 2-3x faster,
+        the labelled throughput option; bf16 is then the overflow-safe choice with real SDXL weights."""
         super().__init__()
         self.config = cfg or VaeConfig.sdxl()
         self._dtype = dtype
+        self.upcast = upcast
         c = self.config.latent_channels
         self.post_quant_conv = nn.Module()
         self.post_quant_conv.weight = nn.Parameter(torch.empty(c, c, 1, 1, dtype=torch.float32, device=device), requires_grad=False)
         self.post_quant_conv.bias = nn.Parameter(torch.empty(c, dtype=torch.float32, device=device), requires_grad=False)
-        self.decoder = _Decoder(self.config, dtype, device)
+        self.decoder = _Decoder(self.config, dtype, device, up_dtype=torch.float32 if upcast else None)
         self._packed = {}
 
     @property
@@ -193,6 +200,8 @@ class AutoencoderKLDecoder(nn.Module):
         x = d.mid_block.resnets[0](x)
         x = d.mid_block.attentions[0](x)
         x = d.mid_block.resnets[1](x)
+        if self.upcast:
+            x = ops.cast_f32(x)                                                 # `sample.to(upscale_dtype)` of diffusers' Decoder.forward
         for blk in d.up_blocks:
             x = blk(x)
         x = d.conv_norm_out(x, silu=True)

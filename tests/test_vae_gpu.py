@@ -117,3 +117,60 @@ def test_pipeline_decodes_through_the_vae(dev):
     assert img.shape == (lat.shape[0], 3, lat.shape[2] * up, lat.shape[3] * up) and img.dtype == torch.float32
     assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
     assert torch.equal(img, vae.decode_latents(lat))
+
+
+# ------------------------------------------------------------------ round 2: the reference's fp32 ("upcast") decode
+def test_fp32_kernels_match_torch_fp32(dev):
+    """omg_conv2d_f32 (f32-input MFMA), fp32 GroupNorm(+SiLU), fp32 conv_out, cast: vs torch fp32 on the CPU.  The MFMA's products are
+    exact fp32 and accumulate in fp32 in a different order than torch's: tolerance = fp32 summation noise, not 16-bit rounding."""
+    g = torch.Generator().manual_seed(0)
+    for (B, H, Cin, Cout, k, ups) in [(2, 16, 128, 128, 3, False), (1, 24, 256, 128, 3, True), (2, 20, 64, 96, 1, False), (1, 33, 32, 260, 3, False)]:
+        x = torch.randn(B, H, H, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) * (k * k * Cin) ** -0.5
+        b = torch.randn(Cout, generator=g)
+        Ho = 2 * H if ups else H
+        res = torch.randn(B, Ho, Ho, Cout, generator=g)
+        y = ops.conv2d_f32(x.to(dev), ops.pack_conv_weight(w.to(dev)), k, upsample=ups, bias=b.to(dev), residual=res.to(dev))
+        xin = x.permute(0, 3, 1, 2)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        ref = F.conv2d(xin.double(), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1) + res.double()
+        err = (y.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5, (B, H, Cin, Cout, k, ups, err)
+    x = torch.randn(2, 40, 40, 128, generator=g) * 3 + 1
+    ga, be = torch.randn(128, generator=g), torch.randn(128, generator=g)
+    y = ops.groupnorm(x.to(dev), ga.to(dev), be.to(dev), 32, 1e-6, silu=True)
+    ref = F.silu(F.group_norm(x.permute(0, 3, 1, 2).double(), 32, ga.double(), be.double(), 1e-6)).permute(0, 2, 3, 1)
+    assert y.dtype == torch.float32 and (y.cpu().double() - ref).abs().max() < 2e-5
+    w = torch.randn(3, 128, 3, 3, generator=g) * 0.03
+    b3 = torch.randn(3, generator=g)
+    yo = ops.conv_out(x.to(dev), w.permute(0, 2, 3, 1).contiguous().to(dev), b3.to(dev))
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b3.double(), padding=1)
+    assert (yo.cpu().double() - ref).abs().max() < 5e-5
+    h = (torch.randn(4, 8, 8, 64, generator=g)).half()
+    assert torch.equal(ops.cast_f32(h.to(dev)).cpu(), h.float())
+
+
+@pytest.mark.parametrize("cfg_name", ["tiny", "sdxl"])
+def test_upcast_decode_matches_oracle(dev, cfg_name):
+    """upcast=True = the reference's decode (lora_pipeline.py:639-652): post_quant_conv / conv_in / mid block in fp16, up blocks,
+    conv_norm_out and conv_out in fp32 with fp32 weights.  The oracle gets fp16-rounded weights for the fp16 part only."""
+    cfg_o = getattr(ov.VaeConfig, cfg_name)()
+    cfg_p = getattr(VaeConfig, cfg_name)()
+    sd = ov.init_state_dict(cfg_o, seed=4)
+    vae = AutoencoderKLDecoder(cfg_p, dtype=torch.float16, device=dev, upcast=True)
+    vae.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    assert vae.decoder.up_blocks[0].resnets[0].conv1.weight.dtype == torch.float32 and vae.decoder.mid_block.resnets[0].conv1.weight.dtype == torch.float16
+    sd_r = {k: (v.half().float() if k.startswith(("decoder.conv_in", "decoder.mid_block")) else v) for k, v in sd.items()}
+    z = torch.randn(2 if cfg_name == "tiny" else 1, 4, 16, 16, generator=torch.Generator().manual_seed(5))
+    ref = ov.decode(sd_r, cfg_o, z).float()
+    out = vae.decode(z.to(dev)).float().cpu()
+    rms = ref.pow(2).mean().sqrt()
+    e_rms, e_max = ((out - ref).pow(2).mean().sqrt() / rms).item(), ((out - ref).abs().max() / rms).item()
+    lo = AutoencoderKLDecoder(cfg_p, dtype=torch.float16, device=dev)
+    lo.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+    out16 = lo.decode(z.to(dev)).float().cpu()
+    e16 = ((out16 - ref).pow(2).mean().sqrt() / rms).item()
+    print(f"VAE decode {cfg_name}: upcast (fp16 mid, fp32 up blocks) rms err {e_rms:.2e} max {e_max:.2e}; all-fp16 rms err {e16:.2e}")
+    assert e_rms < 5e-3 and e_max < 3e-2
+    assert e_rms < e16

@@ -1,0 +1,127 @@
+"""Measurements beside the headline bench line (run on the GPU box, results under profiles/):
+
+  ips      images/s of the headline workload at 1, 4 and 8 lock-step requests per step (1 = the reference's own call shape)
+  both     stage 1 + stage 2 per image: 50 plain steps, then the stage-2 call; segmentation excluded
+  instantid  BASELINE configs[2]: OMG + InstantID, 2 identities, 1024^2, 30 Euler steps, guidance 3.0: IdentityNet (ControlNet)
+             on every concept pass + IP-Adapter cross-attention with 16 face tokens
+
+python tools/bench_extras.py ips|both|instantid [--steps K] [--dtype fp16|fp8]   -> one JSON line per measurement
+"""
+import argparse, contextlib, io, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from omg_amd import controller as pc
+from omg_amd.pipeline import ConceptModels, LoraMultiConceptPipeline, revise_regionally_controlnet_forward
+from omg_amd.schedulers import make_scheduler
+from omg_amd.synthetic import c2_inputs, c2_masks, make_concept_models
+from omg_amd.unet import UNet2DConditionModel, UNetConfig
+
+ap = argparse.ArgumentParser()
+ap.add_argument("what", choices=["ips", "both", "instantid"])
+ap.add_argument("--steps", type=int, default=1)
+ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp8"])
+ap.add_argument("--ips", default="1,4,8")
+a = ap.parse_args()
+dev, dt = torch.device("cuda:0"), torch.float16
+unet = UNet2DConditionModel(UNetConfig.sdxl(), dtype=dt, device=dev).init_synthetic_(seed=0)
+if a.dtype == "fp8":
+    unet.set_linear_precision("mx8")
+P = "a man and a woman walking on the street"
+ctl = pc.AttentionReplace([P, P], 50, {"default_": 1.0}, 0.4, 32, 32, device=dev, dtype=dt)
+with contextlib.redirect_stdout(io.StringIO()):
+    revise_regionally_controlnet_forward(unet, ctl)
+masks = c2_masks(1024, 1024, device=dev)
+from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
+vae = AutoencoderKLDecoder(VaeConfig.sdxl(), dtype=torch.bfloat16, device=dev).init_synthetic_(seed=1)
+
+
+def reqs_for(n, seed0):
+    out = []
+    for j in range(n):
+        r = c2_inputs(unet, seed=seed0 * 16 + j)
+        r["region_masks"] = masks
+        out.append(r)
+    return out
+
+
+def timed(fn, steps):
+    fn(0)                                        # warm-up (captures the graphs)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps):
+        fn(1 + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+if a.what in ("ips", "both"):
+    concept = make_concept_models(unet, n_concepts=2, rank=64)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
+    kw = dict(height=1024, width=1024, num_inference_steps=50, guidance_scale=7.5, cross_attention_kwargs={"scale": 0.8}, controller=ctl,
+              concept_models=concept, lora_list=["concept0", "concept1"], styleL=False, use_graph=True)
+
+    def stage2(reqs):
+        ctl.reset()
+        lat = pipe.generate_many(reqs, stage=2, **kw)
+        for j in range(lat.shape[0]):
+            vae.decode_latents(lat[j])
+        return lat
+
+    if a.what == "ips":
+        for n in [int(x) for x in a.ips.split(",")]:
+            sec = timed(lambda i: stage2(reqs_for(n, i)), a.steps)
+            print(json.dumps({"measurement": "images_per_step", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec, "sec_per_step": sec,
+                              "workload": "BASELINE configs[1], stage-2 call + VAE decode of both images", "steps_timed": a.steps}), flush=True)
+    else:
+        n = 8
+        def both(i):
+            rq = reqs_for(n, i)
+            ctl.reset()
+            lat1 = pipe.generate_many([{k: v for k, v in r.items() if k != "region_masks"} for r in rq], stage=1, **kw)     # stage 1: 50 plain steps
+            for j in range(n):
+                vae.decode_latents(lat1[j])                                     # the stage-1 image the segmenter would look at
+            stage2(rq)
+        sec = timed(both, a.steps)
+        print(json.dumps({"measurement": "stage1_plus_stage2", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec, "sec_per_step": sec,
+                          "workload": "BASELINE configs[1]: stage 1 (50 plain steps, decode) + stage 2 (fusion for i > 15, decode) per image; "
+                                      "detection / segmentation between the stages excluded; 3.626 PFLOP per image (SURVEY 8d)", "steps_timed": a.steps}), flush=True)
+else:
+    from omg_amd.controlnet import ControlNetModel
+    from omg_amd.ip_adapter import IPAdapter
+    idn = ControlNetModel(UNetConfig.sdxl(), dtype=dt, device=dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    for name, p in idn.named_parameters():
+        if name.endswith(".weight") and p.dim() >= 2:
+            w = torch.randn(p.shape, generator=g, device=dev) * p[0].numel() ** -0.5
+        elif name.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(p.shape, generator=g, device=dev)
+        else:
+            w = 0.1 * torch.randn(p.shape, generator=g, device=dev)
+        p.data.copy_(w.to(p.dtype))
+    idn.invalidate_packed()
+    IPAdapter(unet, num_tokens=16, scale=0.8).init_synthetic_(seed=3)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("euler"))
+    concept = ConceptModels(unet, None)
+    n = 8
+
+    def reqs(i):
+        out = []
+        gg = torch.Generator().manual_seed(1000 + i)
+        for j in range(n):
+            r = c2_inputs(unet, seed=i * 16 + j)
+            r["region_masks"] = masks
+            r["region_image_embeds"] = [torch.randn(2, 16, 2048, generator=gg).to(dt).to(dev) for _ in range(2)]
+            r["kps_image"] = torch.rand(1, 3, 1024, 1024, generator=gg)
+            out.append(r)
+        return out
+
+    def run(i):
+        ctl.reset()
+        lat = pipe.generate_many(reqs(i), height=1024, width=1024, num_inference_steps=30, guidance_scale=3.0, controller=ctl, concept_models=concept,
+                                 stage=2, lora_list=["id0", "id1"], styleL=False, identitynet=idn, identitynet_conditioning_scale=0.8, use_graph=True)
+        for j in range(n):
+            vae.decode_latents(lat[j])
+    sec = timed(run, a.steps)
+    print(json.dumps({"measurement": "config2_instantid", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec, "sec_per_step": sec,
+                      "workload": "BASELINE configs[2]: OMG + InstantID, 2 identities, 1024^2, 30 Euler steps, guidance 3.0, IdentityNet on each concept pass "
+                                  "(14 fused steps), IP-Adapter (16 face tokens), stage-2 call + VAE decode; 1.361 PFLOP per image (SURVEY 8d)",
+                      "steps_timed": a.steps}), flush=True)
