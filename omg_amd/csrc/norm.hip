@@ -15,7 +15,7 @@ constexpr int GN_MAX_CHUNKS = 1024;    // partial-sum chunks per sample (64 unti
 
 struct GnP {
   const char* X1; int C1; const char* X2; int C2;
-  int B, HW, G, cpg, nvec, tpp, vpt, pr, nchunk, ppc;
+  int B, HW, G, cpg, nvec, tpp, vpt, pr, nchunk, ppc, b0;
   float eps; const char* gamma; const char* beta; int silu;
   float* ws; char* Y;
 };
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnP p) {
   const int C = p.C1 + p.C2;
   const int tid = threadIdx.x;
   const int prow = tid / p.tpp, tv = tid - prow * p.tpp;
-  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int chunk = blockIdx.x, b = p.b0 + blockIdx.y;
   const int pix0 = chunk * p.ppc;
   const int pix1 = min(p.HW, pix0 + p.ppc);
   float s[2][8], q[2][8];
@@ -43,15 +43,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnP p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[v][e] = 0.f; q[v][e] = 0.f; }
   if (prow < p.pr) {
-    for (int pix = pix0 + prow; pix < pix1; pix += p.pr) {
+    // four pixels per trip: four independent 16-byte loads in flight per lane (one load per trip left the kernel latency-bound
+    // at 0.8-2 TB/s); the accumulation order over pixels is unchanged
+    for (int pix = pix0 + prow; pix < pix1; pix += 4 * p.pr) {
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
         const int vec = tv + v * p.tpp;
         if (v < p.vpt && vec < p.nvec) {
-          float f[8];
-          gn_load<T>(p, b, pix, vec, f);
+          float f[4][8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { s[v][e] += f[e]; q[v][e] += f[e] * f[e]; }
+          for (int u = 0; u < 4; ++u) {
+            const int px = pix + u * p.pr;
+            if (px < pix1) gn_load<T>(p, b, px, vec, f[u]);
+            else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[u][e] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[v][e] += f[u][e]; q[v][e] += f[u][e] * f[u][e]; }
         }
       }
     }
@@ -81,7 +93,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
   __shared__ float mean_s[64], rstd_s[64];
   const int tid = threadIdx.x;
-  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int chunk = blockIdx.x, b = p.b0 + blockIdx.y;
   const int C = p.C1 + p.C2;
   if (tid < p.G) {
     double ss = 0.0, qq = 0.0;
@@ -117,20 +129,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
   }
   const int pix0 = chunk * p.ppc;
   const int pix1 = min(p.HW, pix0 + p.ppc);
-  for (int pix = pix0 + prow; pix < pix1; pix += p.pr) {
+  for (int pix = pix0 + prow; pix < pix1; pix += 4 * p.pr) {
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
       const int vec = tv + v * p.tpp;
       if (v < p.vpt && vec < p.nvec) {
-        float f[8];
-        gn_load<T>(p, b, pix, vec, f);
+        float f[4][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float y = f[e] * sc[v][e] + sh[v][e];
-          if (p.silu) y = silu_f(y);
-          f[e] = y;
+        for (int u = 0; u < 4; ++u) {
+          const int px = pix + u * p.pr;
+          if (px < pix1) gn_load<T>(p, b, px, vec, f[u]);
         }
-        store8<T>(p.Y + (((long)b * p.HW + pix) * C + vec * 8) * (long)sizeof(T), f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int px = pix + u * p.pr;
+          if (px < pix1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float y = f[u][e] * sc[v][e] + sh[v][e];
+              if (p.silu) y = silu_fast(y);
+              f[u][e] = y;
+            }
+            store8<T>(p.Y + (((long)b * p.HW + px) * C + vec * 8) * (long)sizeof(T), f[u]);
+          }
+        }
       }
     }
   }
@@ -303,7 +325,7 @@ extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, 
   p.tpp = p.vpt == 1 ? p.nvec : (p.nvec + 1) / 2;
   p.pr = 256 / p.tpp;
   long elems = (long)HW * C;
-  int nchunk = (int)((elems + 16383) / 16384);
+  int nchunk = (int)((elems + 32767) / 32768);
   if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;
   if (nchunk > HW) nchunk = HW;
   if (nchunk < 1) nchunk = 1;
@@ -313,17 +335,24 @@ extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, 
   p.eps = eps; p.gamma = (const char*)gamma; p.beta = (const char*)beta; p.silu = silu;
   p.ws = workspace; p.Y = (char*)Y;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(nchunk, B);
   const size_t lds = (size_t)2 * p.pr * C * sizeof(float);
-  if (dtype == OMG_F16) {
-    OMG_LAUNCH(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
-    OMG_LAUNCH(gn_apply_kernel<f16>, grid, dim3(256), 0, s, p);
-  } else if (dtype == OMG_BF16) {
-    OMG_LAUNCH(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
-    OMG_LAUNCH(gn_apply_kernel<bf16>, grid, dim3(256), 0, s, p);
-  } else {          // fp32 storage: the up-blocks of the upcast VAE decode (lora_pipeline.py:639-652)
-    OMG_LAUNCH(gn_stats_kernel<float>, grid, dim3(256), lds, s, p);
-    OMG_LAUNCH(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
+  // one pair of launches for the whole batch.  Tried and rejected (round 2): statistics + apply on groups of samples sized to the
+  // 256 MiB Infinity Cache so that the apply pass re-reads x on-die — 16 % SLOWER at B = 64 (smaller grids, 2 us per extra boundary).
+  long sub = B;
+  for (int b0 = 0; b0 < B; b0 += (int)sub) {
+    p.b0 = b0;
+    const int nb = B - b0 < (int)sub ? B - b0 : (int)sub;
+    dim3 grid(nchunk, nb);
+    if (dtype == OMG_F16) {
+      OMG_LAUNCH(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
+      OMG_LAUNCH(gn_apply_kernel<f16>, grid, dim3(256), 0, s, p);
+    } else if (dtype == OMG_BF16) {
+      OMG_LAUNCH(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
+      OMG_LAUNCH(gn_apply_kernel<bf16>, grid, dim3(256), 0, s, p);
+    } else {          // fp32 storage: the up-blocks of the upcast VAE decode (lora_pipeline.py:639-652)
+      OMG_LAUNCH(gn_stats_kernel<float>, grid, dim3(256), lds, s, p);
+      OMG_LAUNCH(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
+    }
   }
   return omg_check_launch("groupnorm");
 }
