@@ -91,6 +91,23 @@ OMG_DEV void store_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, const floa
   // the wait state only when soffset is an immediate.
   __builtin_amdgcn_raw_buffer_store_b128(sw, rs, off + soff, 0, 0);
 }
+// tools only (dbg 2048 / 4096): the same 16 bytes per lane written in a row-contiguous pattern (wrong placement, every byte of
+// the tile still written once) and / or with the non-temporal bit — prices a transposed, streaming epilogue before it is built
+template <typename T>
+OMG_DEV void store_runs_dbg(__amdgpu_buffer_rsrc_t rs, int off, const float (&f)[8], bool nt, int pol) {
+  u32x4 pk = pack8<T>(f);
+  switch (pol) {
+    case 1: __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 1); break;      // sc0
+    case 2: __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 16); break;     // sc1
+    case 3: __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 17); break;     // sc0 sc1
+    case 4: __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 3); break;      // nt sc0
+    case 5: __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 18); break;     // nt sc1
+    case 6: __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 19); break;     // nt sc0 sc1
+    default:
+      if (nt) __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(pk, rs, off, 0, 0);
+  }
+}
 
 // Accumulators start at the bias instead of zero (one add per output saved in the epilogue, where a wave has no
 // partner to hide VALU latency behind).  Same register <-> element map as epilogue_direct.
@@ -123,11 +140,62 @@ struct EpiCtx {
   __amdgpu_buffer_rsrc_t rsC, rsR, rsG;
   int hi, l31, wm0, m_end;
   int lane_col;                 // byte offset of the lane's unit (j = 0, pr = 0) inside a row
+  int wn0, n_out;               // first output column of the wave tile / width of the output matrix
+  char* xl;                     // XE: this wave's 8 KB of LDS for the row-block transposition
   int voob[NT][2];              // 0 where the unit's columns are inside the matrix, EPI_OOB where they are not
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// XE (v7 256x256 only): row-contiguous, non-temporal stores.  The register-direct store above writes 32 rows x 32 bytes per
+// instruction; with the non-temporal bit those partial lines go to DRAM one by one (3-4x slower), without it the C tile's
+// 128 KB per CU and round (4 MB per XCD = the whole L2) evicts the A / W lines the next tile's K loop wants (K loop
+// 36.8 -> 33.4 us on the GEGLU-sized GEMM once the stores stream, tools/gemm_timeline.py bits 2048 | 4096).  So a row block
+// (32 rows x ROWB bytes of one wave) is exchanged through 8 KB of wave-private LDS: a lane writes its two 8-byte runs of
+// each unit (no v_permlane32_swap needed), reads back 16 bytes of a row whose ROWB / 16 pieces sit in neighbouring lanes,
+// and stores 1 KB per instruction as whole 128- / 256-byte row segments with `nt`.  Same values, same packing, same bits.
+// (The residual stays on its register-direct loads: fetching it as row segments and handing it round through the same LDS
+// image was measured 3-7 % slower on the N = 1280 / 640 projections.)
+// LDS image: row r at r * ROWB; 16-byte piece c of row r at piece (c ^ swz(r)), 8-byte halves exchanged when r >= 16
+// (32 lanes x 8 bytes of a ds_write_b64 then cover all 64 banks; the ds_read_b128 of 16 lanes cover 256 contiguous bytes).
+template <typename T, int ROWB>
+OMG_DEV void xe_put(const EpiCtx<4>& cx, int piece, const float (&v)[8]) {
+  const u32x4 pk = pack8<T>(v);                     // pk[0..1] = run 0 (columns +0..3), pk[2..3] = run 1 (columns +8..11), both + 4 hi
+  const int sw = ROWB == 256 ? (cx.l31 & 15) : ((cx.l31 >> 1) & 7);
+  char* b = cx.xl + cx.l31 * ROWB + ((cx.hi ^ (cx.l31 >> 4)) << 3);
+  const int c0 = piece ^ sw;
+  const u32x2 r0 = {pk[0], pk[1]}, r1 = {pk[2], pk[3]};
+  *(u32x2*)(b + (c0 << 4)) = r0;
+  *(u32x2*)(b + ((c0 ^ 1) << 4)) = r1;
+}
+template <typename T, int ROWB>
+OMG_DEV void xe_flush(const GemmP& p, const EpiCtx<4>& cx, int i, int col0) {
+  constexpr int LPR = ROWB / 16;                    // lanes per row: 16 (256-byte rows) or 8 (GEGLU: 128-byte rows)
+  constexpr int RPI = 64 / LPR;                     // rows per store instruction
+  constexpr int NU = 32 / RPI;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS serves a wave in order; this is the compiler's fence
+  const int lane = cx.hi * 32 + cx.l31;
+  const int rq = lane / LPR, c = lane % LPR;
+  const bool col_ok = col0 + 8 * c < cx.n_out && !(p.dbg & 1024);
+  const int colb = (col0 + 8 * c) * 2;
+  u32x4 d[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int rr = u * RPI + rq;
+    const int sw = ROWB == 256 ? (rr & 15) : ((rr >> 1) & 7);
+    const u32x4 x = *(const u32x4*)(cx.xl + rr * ROWB + ((c ^ sw) << 4));
+    if (u * RPI >= 16) d[u] = u32x4{x[2], x[3], x[0], x[1]}; else d[u] = x;     // rows >= 16 hold their halves exchanged
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int gm = cx.wm0 + i * 32 + u * RPI + rq;
+    const int off = (gm < cx.m_end && col_ok) ? gm * (int)p.ldc * 2 + colb : EPI_OOB;
+    __builtin_amdgcn_raw_buffer_store_b128(d[u], cx.rsC, off, 0, 2);            // nt: stream past L2
+  }
+  asm volatile("" ::: "memory");
+}
 // SiLU / per-row group bias / residual decided at run time inside the unit loop: the rare combinations
-template <typename T, int MT, int NT, bool RS, bool GENERIC>
+template <typename T, int MT, int NT, bool RS, bool GENERIC, bool XE = false>
 OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, bool has_gb) {
   const float osc = p.out_scale;
   const bool has_rs = GENERIC ? p.residual != nullptr : RS;
@@ -180,14 +248,23 @@ OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<N
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= osc;
         }
+        if constexpr (XE) {
+          xe_put<T, 256>(cx, 4 * j + 2 * pr, v);
+        } else if (p.dbg & (2048 | 4096 | 0xe000)) {
+          const int lane_ = cx.hi * 32 + cx.l31, u_ = j * 2 + pr;
+          const int off_ = (p.dbg & 2048) ? (cx.wm0 + i * 32 + u_ * 4 + (lane_ >> 4)) * (int)p.ldc * 2 + (cx.lane_col - cx.hi * 16) + (lane_ & 15) * 16
+                                          : (ro | cx.voob[j][pr]) + (j * 32 + pr * 16) * 2;
+          store_runs_dbg<T>(cx.rsC, off_, v, (p.dbg & 4096) != 0, (p.dbg >> 13) & 7);
+        } else
         store_runs<T>(cx.rsC, ro | cx.voob[j][pr], (j * 32 + pr * 16) * 2, v);
         __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from hoisting every accumulator read to the top (spills)
       }
+    if constexpr (XE) xe_flush<T, 256>(p, cx, i, cx.wn0);
   }
 #undef OMG_FETCH_RES
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool XE = false>
 OMG_DEV void epilogue_geglu(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, int lane_col_g) {
   const float osc = p.out_scale;
 #pragma unroll
@@ -201,14 +278,17 @@ OMG_DEV void epilogue_geglu(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = acc[i][2 * b][pr * 8 + e] * gelu_f(acc[i][2 * b + 1][pr * 8 + e]) * osc;
-        store_runs<T>(cx.rsC, ro | cx.voob[2 * b][pr], (b * 32 + pr * 16) * 2, o);
+        if constexpr (XE) xe_put<T, 128>(cx, 4 * b + 2 * pr, o);
+        else store_runs<T>(cx.rsC, ro | cx.voob[2 * b][pr], (b * 32 + pr * 16) * 2, o);
         __builtin_amdgcn_sched_barrier(0);
       }
+    if constexpr (XE) xe_flush<T, 128>(p, cx, i, cx.wn0 >> 1);
   }
 }
 
-template <typename T, int MT, int NT>
-OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0, int m_end, bool has_gb) {
+template <typename T, int MT, int NT, bool XE = false>
+OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0, int m_end, bool has_gb, char* xl = nullptr) {
+  static_assert(!XE || NT == 4, "the transposed epilogue is written for 128-column wave tiles");
   const bool geglu = p.act == OMG_ACT_GEGLU;
   const int n_out = geglu ? p.N / 2 : p.N;
   EpiCtx<NT> cx;
@@ -223,14 +303,15 @@ OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, in
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) cx.voob[j][pr] = (wn0 + j * 32 + pr * 16 + cx.hi * 8 < p.N && !(p.dbg & 1024)) ? 0 : EPI_OOB;   // dbg 1024 (tools): drop all stores
   cx.lane_col = (wn0 + cx.hi * 8) * 2;
+  cx.wn0 = wn0; cx.n_out = n_out; cx.xl = xl;
   if (geglu) {
-    epilogue_geglu<T, MT, NT>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);   // GEGLU output is half as wide
+    epilogue_geglu<T, MT, NT, XE>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);   // GEGLU output is half as wide
   } else if (has_gb || p.act == OMG_ACT_SILU) {
-    epilogue_rows<T, MT, NT, false, true>(p, acc, cx, has_gb);
+    epilogue_rows<T, MT, NT, false, true, XE>(p, acc, cx, has_gb);
   } else if (p.residual != nullptr) {
-    epilogue_rows<T, MT, NT, true, false>(p, acc, cx, false);
+    epilogue_rows<T, MT, NT, true, false, XE>(p, acc, cx, false);
   } else {
-    epilogue_rows<T, MT, NT, false, false>(p, acc, cx, false);
+    epilogue_rows<T, MT, NT, false, false, XE>(p, acc, cx, false);
   }
 }
 

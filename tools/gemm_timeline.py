@@ -40,4 +40,14 @@ print(f"prologue (start -> stage 0 landed) {mean(pro)/100:.2f} us   main loop {m
       f"gap to next block on the slot {mean(gap)/100:.2f} us   kernel span {(max(r[3] for r in rows) - t_min)/100:.1f} us")
 k0 = sorted(cus)[0]
 print("one slot:", [(e[0], e[1], e[2], e[3]) for e in cus[k0][:6]])
+lib.omg_debug_set_gemm_variant(15 | (extra << 8))
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ops.gemm(x, w, out=out)
+s.record()
+for _ in range(10):
+    ops.gemm(x, w, out=out)
+e.record()
+torch.cuda.synchronize()
+ms = s.elapsed_time(e) / 10
+print(f"untimed-stamp launch: {ms*1000:.1f} us = {2*M*N*K/ms/1e9:.0f} TF/s")
 lib.omg_debug_set_gemm_variant(0)
