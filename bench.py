@@ -66,6 +66,55 @@ def cpu_baseline(args):
             "torch": torch.__version__}
 
 
+class PowerSampler:
+    """Socket power and shader clock during the timed region (rocm-smi polled from a side thread, rank 0 only): the MFMA peak
+    the roofline is priced against assumes 2.4 GHz; under dense MFMA load the part sits at its power cap and clocks lower
+    (profiles/r02_power_probe.log), so the line also carries the clock the kernels actually ran at."""
+    def __init__(self, device_index, period=1.0):
+        import threading
+        self.dev, self.period, self.rows, self._stop = device_index, period, [], False
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re, subprocess
+        while not self._stop:
+            try:
+                o = subprocess.run(["rocm-smi", "-d", str(self.dev), "-c", "-P", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+                card = next(iter(json.loads(o).values()))
+                row = {}
+                for k, v in card.items():
+                    kl = k.lower()
+                    m = re.search(r"[-+]?\d+(\.\d+)?", str(v))
+                    if m is None:
+                        continue
+                    if "sclk clock speed" in kl:
+                        row["sclk"] = float(m.group())
+                    elif "max graphics package power" in kl:
+                        row["cap"] = float(m.group())
+                    elif "power (w)" in kl and "max" not in kl:
+                        row["w"] = float(m.group())
+                if row:
+                    self.rows.append(row)
+            except Exception:      # noqa: BLE001 - no rocm-smi, odd output: the line is simply reported without power
+                pass
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._th.join(timeout=15)
+
+    def summary(self):
+        def avg(k):
+            v = [r[k] for r in self.rows if k in r]
+            return sum(v) / len(v) if v else None
+        return {"avg_w": avg("w"), "cap_w": avg("cap"), "avg_sclk_mhz": avg("sclk"), "samples": len(self.rows), "nominal_sclk_mhz": 2400.0,
+                "source": "rocm-smi -c -P polled once a second during the timed region"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +133,8 @@ def main():
     ap.add_argument("--by-shape", default="", help="also write the roofline leg's per-shape table (ms per bench step, TF/s) to this file")
     ap.add_argument("--no-vae", action="store_true", help="stop at the latents (skip the VAE decode that ends the reference's stage-2 call)")
     ap.add_argument("--vae-16bit", action="store_true", help="decode in bf16 storage instead of the reference's fp32 up blocks (faster, NOT the reference's precision)")
+    ap.add_argument("--fp8-linear-only", action="store_true", help="with --dtype fp8: keep every convolution in fp16 (round-2 first fp8 line)")
+    ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for power / clock during the timed region")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
 
@@ -104,6 +155,8 @@ def main():
     unet = UNet2DConditionModel(cfg, dtype=dt, device=dev).init_synthetic_(seed=0)
     if args.dtype == "fp8":
         unet.set_linear_precision("mx8")
+        if not args.fp8_linear_only:
+            unet.set_conv_precision("mx8")
     HW = cfg.sample_size * 8
     P = "a man and a woman walking on the street"
     ctl = pc.AttentionReplace([P, P], 50, cross_replace_steps={"default_": 1.0}, self_replace_steps=0.4,
@@ -145,8 +198,11 @@ def main():
     for i in range(args.warmup):
         lat = run_step(inputs[i])
         parallel.gather_latents(lat[:, 1].contiguous(), world * ips, rank, world)
+    sampler = PowerSampler(local) if rank == 0 and not args.no_power else None
     parallel.barrier()
     torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         lat = run_step(inputs[i])
@@ -155,13 +211,16 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if sampler is not None:
+        sampler.__exit__()
     assert torch.isfinite(allimg).all()
     value = world * ips * args.steps / el
 
     out = {"metric": "images/sec @ SDXL 1024^2 50-step, 2-concept mask fusion", "value": value, "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * el / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "fp8 (OCP MX e4m3 operands, fp32 accumulate) on the transformer Linear layers; fp16 elsewhere" if args.dtype == "fp8" else args.dtype,
+           "dtype": ("fp8 (OCP MX e4m3 operands, fp32 accumulate) on the transformer Linear layers" + ("" if args.fp8_linear_only else " and the resnet 3x3 convolutions with Cin % 128 == 0")
+                     + "; fp16 elsewhere") if args.dtype == "fp8" else args.dtype,
            "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: SDXL-base 1024x1024, %d %s steps, 2 concepts + 2 rank-64 LoRAs, masked "
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),
@@ -175,6 +234,8 @@ def main():
                       "main + concept samples of all requests batched per fused step (8 samples per request)"},
            "end_to_end_tflops_per_gpu": (N_MAIN + N_CONCEPT) * SAMPLE_FWD_TFLOP * value / world if not args.tiny else None}
 
+    if sampler is not None:
+        out["power"] = sampler.summary()
     if rank == 0 and not args.no_roofline:
         # instrumented eager passes: HIP events around every GEMM/conv/attention launch of 2 plain and of 2 fused denoising
         # steps, combined with the weights of the timed workload (fusion fires for steps i > 15: 16 plain + 34 fused of 50)
@@ -209,7 +270,7 @@ def main():
                             % ((pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"]) / 1e9))
         except (OSError, KeyError, ValueError):
             pass
-        kname = ("gemm_mx8_kernel (transformer Linear layers, MX-fp8 operands on v_mfma_scale_f32_32x32x64_f8f6f4, per-sample weight slots)"
+        kname = ("gemm_mx8_kernel (transformer Linear layers + resnet convolutions, MX-fp8 operands on v_mfma_scale_f32_32x32x64_f8f6f4, per-sample weight slots)"
                  if args.dtype == "fp8" else "gemm_kernel_v7 / gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)")
         if args.dtype == "fp8":
             traffic, traffic_note = None, "not measured for the MX-fp8 kernel"
@@ -220,6 +281,9 @@ def main():
                            "gemm_ms_per_step": g_ms,
                            "sample": f"HIP events around each launch (eager), 2 plain + 2 fused denoising steps weighted {n_p}:{n_f} as in the timed workload",
                            "attn_kernel": {"achieved": a_fl / (a_ms * 1e-3) / 1e12, "ms_per_step": a_ms}}
+        sclk = (out.get("power") or {}).get("avg_sclk_mhz")
+        if sclk:      # the same fraction against the MFMA peak at the clock the part held during the timed region
+            out["roofline"]["frac_at_measured_clock"] = ach / (peak * sclk / 2400.0)
         if args.dtype == "fp8":      # the 16-bit GEMM family still runs the convolutions (and the K/V, embedding Linears)
             c_ms, c_fl = comb("gemm", "ms"), comb("gemm", "flops")
             out["roofline"]["fp16_gemm_family"] = {"achieved": c_fl / (c_ms * 1e-3) / 1e12, "ms_per_step": c_ms, "peak": PEAK_TFLOPS}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMG_ABI_VERSION 4
+#define OMG_ABI_VERSION 5
 
 enum { OMG_F16 = 0, OMG_BF16 = 1, OMG_F32 = 2 /* only where a signature says so */ };
 
@@ -126,6 +126,24 @@ typedef struct {
 
 int omg_gemm_mx8(const omg_gemm_mx8_args* a, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution of an MX-fp8 NHWC feature map (omg_groupnorm_mx8's output) with MX-fp8 weights
+ * (omg_quant_mx8 of the packed [Cout][ky][kx][Cin] weight, K = 9 Cin) on the block-scaled MFMA: the resnet convolutions
+ * (conv1 with the time-embedding projection as per-sample bias, conv2 with the skip tensor as residual) of BASELINE configs[4].
+ * Output, bias, group_bias and residual are fp16 / bf16 (`dtype`). */
+typedef struct {
+  int32_t dtype;
+  int32_t B, H, W, Cin, Cout;        /* Cin % 128 == 0, Cout % 8 == 0                         */
+  const void* X; const void* x_scale;      /* e4m3 [B*H*W][Cin]; uint32 [Cin/128][B*H*W]      */
+  const void* Wq; const void* w_scale;     /* e4m3 [Cout][9*Cin]; uint32 [9*Cin/128][sw_ld]   */
+  int32_t sw_ld, act;
+  const void* bias;                  /* [Cout] or NULL                                        */
+  const void* group_bias; int64_t ldgb;    /* [B][ldgb] per-sample bias or NULL               */
+  const void* residual;              /* [B*H*W][Cout] or NULL                                 */
+  float out_scale;
+  void* Y;                           /* [B*H*W][Cout]                                         */
+} omg_conv2d_mx8_args;
+int omg_conv2d_mx8(const omg_conv2d_mx8_args* a, void* stream);
+
 /* ------------------------------------------------------------------------
  * omg_conv2d — NHWC implicit-GEMM convolution (3x3 pad 1, or 1x1), stride 1|2,
  * optional fused nearest-2x upsample of the input and fused channel-concat of
@@ -213,6 +231,16 @@ int omg_layernorm(int dtype, const void* X, int64_t ldx, int M, int C, float eps
 int omg_layernorm_mx8(int dtype, const void* X, int64_t ldx, int M, int C, float eps,
                       const void* gamma, const void* beta, void* Q, int64_t ldq,
                       void* scales, int s_ld, void* stream);
+
+/* GroupNorm(+SiLU)(+concat) whose consumer is omg_conv2d_mx8 (the resnets' norm1 -> conv1, norm2 -> conv2, diffusers 0.25.0
+ * resnet.py ResnetBlock2D.forward): y, rounded to `dtype` exactly as omg_groupnorm stores it, is written as MX-fp8 bytes
+ * Q[B*HW][Cq] and per-pixel scales S[Cq/128][B*HW] dwords (byte j of a dword: the E8M0 scale of channels 128 k + 32 j .. + 31);
+ * C = C1 + C2 must be a multiple of 32, Cq = C rounded up to a multiple of 128, and the Cq - C pad channels are written as
+ * zeros with scale byte 0 (SDXL's 320- and 960-channel maps: Cq = 384, 1024; the convolution weight is padded alike). */
+int omg_groupnorm_mx8(int dtype, const void* X1, int C1, const void* X2, int C2,
+                      int B, int HW, int groups, float eps,
+                      const void* gamma, const void* beta, int silu,
+                      float* workspace, void* Q, void* scales, void* stream);
 
 /* ------------------------------------------------------------------------
  * fp32 path of the VAE decode.  The reference upcasts the VAE before decoding ("it overflows in float16", upcast_vae at

@@ -47,6 +47,16 @@ class GemmMx8Args(C.Structure):
     ]
 
 
+class Conv2dMx8Args(C.Structure):
+    _fields_ = [
+        ("dtype", c_i32), ("B", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32), ("Cout", c_i32),
+        ("X", c_vp), ("x_scale", c_vp), ("Wq", c_vp), ("w_scale", c_vp),
+        ("sw_ld", c_i32), ("act", c_i32),
+        ("bias", c_vp), ("group_bias", c_vp), ("ldgb", c_i64), ("residual", c_vp),
+        ("out_scale", c_f32), ("Y", c_vp),
+    ]
+
+
 class Conv2dArgs(C.Structure):
     _fields_ = [
         ("dtype", c_i32), ("B", c_i32), ("Hin", c_i32), ("Win", c_i32),
@@ -94,6 +104,8 @@ SYMBOLS = {
     "omg_gemm": (c_i32, [C.POINTER(GemmArgs), c_vp]),
     "omg_quant_mx8": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp]),
     "omg_gemm_mx8": (c_i32, [C.POINTER(GemmMx8Args), c_vp]),
+    "omg_conv2d_mx8": (c_i32, [C.POINTER(Conv2dMx8Args), c_vp]),
+    "omg_groupnorm_mx8": (c_i32, [c_i32, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "omg_conv2d": (c_i32, [C.POINTER(Conv2dArgs), c_vp]),
     "omg_conv2d_f32": (c_i32, [C.POINTER(Conv2dF32Args), c_vp]),
     "omg_cast_f32": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_vp]),
@@ -151,7 +163,7 @@ def lib() -> C.CDLL:
         fn = getattr(l, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if l.omg_abi_version() != 4:
+    if l.omg_abi_version() != 5:
         raise OmgHipError("libomg_hip.so ABI version mismatch; rebuild")
     v = os.environ.get("OMG_GEMM_VARIANT")      # debugging/benchmarking aid: force one GEMM tile configuration
     if v:

@@ -321,4 +321,9 @@ OMG_DEV void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, voff, soff, 0, 0);
 }
 
+// 4 bytes per lane (256 contiguous bytes of LDS per instruction): per-row scale dwords of the MX-fp8 convolution
+OMG_DEV void dma4(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 4, voff, soff, 0, 0);
+}
+
 }  // namespace

@@ -45,7 +45,14 @@ OMG_DEV f32x16 mfma_mx8(i32x8 a, i32x8 b, f32x16 c, int sa, int sb, int ks) {
 // D1 = number of the 16 operand DMA instructions of stage kt+2 issued during the LAST k-step of stage kt (the rest follow in
 // k-step 0 of stage kt+1).  The buffer they fill is released by the barrier of stage kt, and they must have landed by the
 // barrier of stage kt+1: a DMA issued in the last k-step has two k-steps (~2000 cycles) to land, one issued in k-step 0 one.
-template <typename T, int D1>
+//
+// CONV = true: the A operand is an NHWC MX-fp8 feature map (bytes [B*H*W][C], C % 128 == 0) read as the implicit GEMM of a 3x3,
+// stride 1, pad 1 convolution: stage kt covers channels 128 (kt % (C/128)) .. + 127 of tap kt / (C/128), row m of the tile
+// reads pixel (y + dy, x + dx) of its sample, and taps outside the map are the descriptor's out-of-range zeros.  A-operand
+// scales are stored per pixel, SA[C/128][B*H*W] dwords (omg_groupnorm_mx8 writes them): every wave fetches the dwords of 64 of
+// the tile's rows with ONE 4-byte-per-lane LDS-DMA per stage at the tap-shifted pixel (out of range: byte 0 = 2^-127, times
+// zeros).  Weights [Cout][9 C] and their scales are those of the Linear path (omg_quant_mx8 of the packed conv weight).
+template <typename T, int D1, bool CONV = false>
 __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
   constexpr int MT = 4, NT = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,32 +92,60 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
   const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride : 0);
   const char* SWp = p.SW + (p.w_adapter_stride != 0 ? (long)adapter * p.sw_adapter_stride * 4 : 0);
   const int nk = p.K / MXK;
+  const int cpt = CONV ? p.C1 / MXK : 1;                   // stages per tap
 
   // ---- descriptors: exact sizes, so rows past the end and nothing else read as zero
-  const long a_bytes = (long)(p.M - 1) * p.lda + p.K;
+  const long a_bytes = CONV ? (long)p.M * p.C1 : (long)(p.M - 1) * p.lda + p.K;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
   const long w_bytes = (long)(p.N - 1) * p.ldw + p.K;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)w_bytes, 0x00020000);
   // scale arrays: [nk][ld] dwords.  Wave 0 stages the A scales, wave 1 the W scales (1 KiB each per stage).
-  const bool sc_wave = w < 2;
-  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(w == 0 ? p.SA : SWp), 0,
-      (int)((long)nk * (w == 0 ? p.sa_ld : p.sw_ld) * 4), 0x00020000);
-  const int s_step = (w == 0 ? p.sa_ld : p.sw_ld) * 4;                 // bytes between stages
-  const int s_rows = (w == 0 ? p.sa_ld : p.sw_ld);
+  // (CONV: wave 1 stages the W scales this way; the A scales are fetched per row by every wave, below.)
+  const bool sA = !CONV && w == 0;
+  const bool sc_wave = CONV ? w == 1 : w < 2;
+  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(sA ? p.SA : SWp), 0,
+      (int)((long)nk * (sA ? p.sa_ld : p.sw_ld) * 4), 0x00020000);
+  const int s_step = (sA ? p.sa_ld : p.sw_ld) * 4;                     // bytes between stages
+  const int s_rows = (sA ? p.sa_ld : p.sw_ld);
   // a lane carries 4 consecutive rows' dwords; rows past the array's row count must not wrap into the next stage's rows
-  const int s_row0 = (w == 0 ? m0 : n0) + lane * 4;
+  const int s_row0 = (sA ? m0 : n0) + lane * 4;
   const int voffS = s_row0 + 3 < s_rows ? s_row0 * 4 : 0x7ffffff0;
-  const int ldoS = MX_SC + (w == 0 ? 0 : 1024);
+  const int ldoS = MX_SC + (sA ? 0 : 1024);
+  // CONV A scales: lane -> row m0 + 64 w + lane of the tile
+  const int hw = CONV ? p.Hout * p.Wout : 1;
+  const __amdgpu_buffer_rsrc_t rsSA = __builtin_amdgcn_make_buffer_rsrc((void*)p.SA, 0, CONV ? (int)((long)cpt * p.M * 4) : 0, 0x00020000);
+  int s_pix = 0, s_yx = 0x7fff0000;
+  if constexpr (CONV) {
+    const int gm = m0 + w * 64 + lane;
+    if (gm < m_end) {
+      const int rem = gm % hw;
+      const int y = rem / p.Wout;
+      s_pix = gm * 4; s_yx = (y << 16) | (rem - y * p.Wout);
+    }
+  }
 
   // ---- operand DMA: one instruction moves 8 rows x 128 B; wave w owns row blocks w, w+4, ..., w+28 of A and of W.
   // Row block i of a wave is 32 rows further: one VGPR offset per operand + an SGPR step (rows past the matrix end are out of
   // the descriptor's range and read as zeros; rows of the next group only feed accumulator rows the epilogue never stores).
   const int prow = lane >> 3, ppos = lane & 7;
   const int dchunk = (ppos ^ ((w & 1) * 4 + (prow >> 1))) * 16;       // ((row >> 1) & 7) with row = (w + 4i) * 8 + prow
-  const int voffA0 = (int)((long)(m0 + w * 8 + prow) * p.lda) + dchunk;
+  const int voffA0 = CONV ? (m0 + w * 8 + prow) * p.C1 + dchunk : (int)((long)(m0 + w * 8 + prow) * p.lda) + dchunk;
   const int voffW0 = (int)((long)(n0 + w * 8 + prow) * p.ldw) + dchunk;
-  const int stepA = (int)(32 * p.lda), stepW = (int)(32 * p.ldw);
+  const int stepA = CONV ? 32 * p.C1 : (int)(32 * p.lda), stepW = (int)(32 * p.ldw);
   const int ldo = w * 1024;
+  int a_yx[8];                   // CONV: (y << 16) | x of the lane's row in each of the wave's 8 A row blocks; rows past the end never pass the bounds test
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    a_yx[d] = 0x7fff0000;
+    if constexpr (CONV) {
+      const int gm = m0 + (w + 4 * d) * 8 + prow;
+      if (gm < m_end) {
+        const int rem = gm % hw;
+        const int y = rem / p.Wout;
+        a_yx[d] = (y << 16) | (rem - y * p.Wout);
+      }
+    }
+  }
 
   const int wm = w >> 1, wn = w & 1;
   f32x16 acc[MT][NT];
@@ -130,13 +165,31 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
   const int sshift = hi * 8;
 
   int koff = 0, kst = 0;
-#define MX_PREP(kt_) do { koff = (kt_) * MXK; kst = (kt_); } while (0)
+  int tdy = 0, tdx = 0, tapoff = 0, stapoff = 0;           // CONV: the stage's tap and its byte offsets into the map / the scale plane
+#define MX_PREP(kt_)                                                                                       \
+  do {                                                                                                     \
+    koff = (kt_) * MXK; kst = (kt_);                                                                       \
+    if constexpr (CONV) {                                                                                  \
+      const int tap_ = (kt_) / cpt; const int cb_ = (kt_) - tap_ * cpt;                                    \
+      tdy = tap_ / 3 - 1; tdx = tap_ - (tap_ / 3) * 3 - 1;                                                 \
+      tapoff = (tdy * p.Wout + tdx) * p.C1 + cb_ * MXK;                                                    \
+      stapoff = (cb_ * p.M + tdy * p.Wout + tdx) * 4;                                                      \
+    }                                                                                                      \
+  } while (0)
+#define MX_INSIDE(yx_) ((unsigned)(((yx_) >> 16) + tdy) < (unsigned)p.Hout && (unsigned)(((yx_) & 0xffff) + tdx) < (unsigned)p.Wout)
 #define MX_DMA(d_, nb_)                                                                                    \
   do {                                                                                                     \
-    if ((d_) < 8) dma16(rsA, (nb_) + ldo + ((d_) & 7) * 4096, voffA0, koff + ((d_) & 7) * stepA);          \
-    else dma16(rsW, (nb_) + MX_TILE + ldo + ((d_) & 7) * 4096, voffW0, koff + ((d_) & 7) * stepW);         \
+    if ((d_) < 8) {                                                                                        \
+      if constexpr (CONV) dma16(rsA, (nb_) + ldo + ((d_) & 7) * 4096,                                      \
+                                MX_INSIDE(a_yx[(d_) & 7]) ? voffA0 + ((d_) & 7) * stepA + tapoff : 0x7ffffff0, 0); \
+      else dma16(rsA, (nb_) + ldo + ((d_) & 7) * 4096, voffA0, koff + ((d_) & 7) * stepA);                 \
+    } else dma16(rsW, (nb_) + MX_TILE + ldo + ((d_) & 7) * 4096, voffW0, koff + ((d_) & 7) * stepW);       \
   } while (0)
-#define MX_DMAS(nb_) do { if (sc_wave) dma16(rsS, (nb_) + ldoS, voffS, kst * s_step); } while (0)
+#define MX_DMAS(nb_)                                                                                       \
+  do {                                                                                                     \
+    if (sc_wave) dma16(rsS, (nb_) + ldoS, voffS, kst * s_step);                                            \
+    if constexpr (CONV) dma4(rsSA, (nb_) + MX_SC + w * 256, MX_INSIDE(s_yx) ? s_pix + stapoff : 0x7ffffff0, 0); \
+  } while (0)
   i32x8 af[2][MT], bf[2][NT];
   int sa[MT], sb[NT];            // scale dwords of the current stage (byte 0: k-step 0, byte 2: k-step 1)
   int san[MT], sbn[NT];          // ... of the next stage, read during the last k-step and moved over at the stage boundary
@@ -220,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
 #undef MX_RD1
 #undef MX_DMAS
 #undef MX_DMA
+#undef MX_INSIDE
 #undef MX_PREP
   epilogue_direct<T, MT, NT>(p, acc, lane, m0 + wm * 128, n0 + wn * 128, m_end, gb_epi);
 }
@@ -272,7 +326,7 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const char* x, long ldx,
 
 int g_mx_d1 = 12;      // measured best of 8 / 12 / 16 on the UNet's shapes (profiles/r02_mx8_bench.log)
 
-template <typename T>
+template <typename T, bool CONV = false>
 int launch_mx8(GemmP p, hipStream_t s, int mrows) {
   constexpr int lds = 2 * MX_STAGE;
   p.tiles_m = (mrows + 255) / 256;
@@ -282,8 +336,8 @@ int launch_mx8(GemmP p, hipStream_t s, int mrows) {
 #define MX_LAUNCH(D1_)                                                                                     \
   do {                                                                                                     \
     static bool attr = false;                                                                              \
-    if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel<T, D1_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
-    OMG_LAUNCH((gemm_mx8_kernel<T, D1_>), dim3(grid), dim3(256), lds, s, p);                               \
+    if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel<T, D1_, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
+    OMG_LAUNCH((gemm_mx8_kernel<T, D1_, CONV>), dim3(grid), dim3(256), lds, s, p);                         \
   } while (0)
   if (g_mx_d1 >= 16) MX_LAUNCH(16);
   else if (g_mx_d1 >= 12) MX_LAUNCH(12);
@@ -339,4 +393,33 @@ extern "C" int omg_gemm_mx8(const omg_gemm_mx8_args* a, void* stream) {
   const int mrows = per_group ? a->rows_per_group : a->M;
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == OMG_F16 ? launch_mx8<f16>(p, s, mrows) : launch_mx8<bf16>(p, s, mrows);
+}
+
+extern "C" int omg_conv2d_mx8(const omg_conv2d_mx8_args* a, void* stream) {
+  OMG_REQUIRE(a != nullptr, "omg_conv2d_mx8: null args");
+  OMG_REQUIRE(a->dtype == OMG_F16 || a->dtype == OMG_BF16, "omg_conv2d_mx8: output dtype");
+  OMG_REQUIRE(a->B >= 0 && a->H > 0 && a->W > 0 && a->H < 32768 && a->W < 32768, "omg_conv2d_mx8: shape");
+  OMG_REQUIRE(a->Cin > 0 && a->Cin % 128 == 0 && a->Cout > 0 && a->Cout % 8 == 0, "omg_conv2d_mx8: Cin % 128 == 0, Cout % 8 == 0");
+  OMG_REQUIRE(a->X && a->x_scale && a->Wq && a->w_scale && a->Y, "omg_conv2d_mx8: null operand");
+  OMG_REQUIRE(a->sw_ld >= a->Cout && a->sw_ld % 4 == 0, "omg_conv2d_mx8: sw_ld");
+  const long M = (long)a->B * a->H * a->W;
+  if (M == 0) return OMG_OK;
+  const long K = 9L * a->Cin;
+  const long lim = 0x7fff0000L;
+  OMG_REQUIRE(M * a->Cin < lim && (long)a->Cout * K < lim && M * a->Cout * 2 < lim && (long)(a->Cin / 128) * M * 4 < lim,
+              "omg_conv2d_mx8: an operand exceeds the 2 GiB buffer-descriptor range");
+  GemmP p{};
+  p.M = (int)M; p.N = a->Cout; p.K = (int)K;
+  p.A = (const char*)a->X; p.lda = a->Cin; p.W = (const char*)a->Wq; p.ldw = K;
+  p.SA = (const char*)a->x_scale; p.sa_ld = (int)M; p.SW = (const char*)a->w_scale; p.sw_ld = a->sw_ld;
+  p.C1 = a->Cin; p.Hin = p.Hout = a->H; p.Win = p.Wout = a->W; p.ksize = 3; p.stride = 1;
+  p.tile_groups = 1; p.rows_per_group = a->H * a->W;
+  p.bias = (const char*)a->bias;
+  p.group_bias = (const char*)a->group_bias; p.ldgb = a->ldgb;
+  if (a->group_bias) OMG_REQUIRE(a->ldgb >= a->Cout, "omg_conv2d_mx8: ldgb");
+  p.residual = (const char*)a->residual; p.ldr = a->Cout;
+  p.act = a->act; p.out_scale = a->out_scale; p.C = (char*)a->Y; p.ldc = a->Cout;
+  OMG_REQUIRE(a->act == OMG_ACT_NONE || a->act == OMG_ACT_SILU, "omg_conv2d_mx8: act");
+  hipStream_t s = (hipStream_t)stream;
+  return a->dtype == OMG_F16 ? launch_mx8<f16, true>(p, s, (int)M) : launch_mx8<bf16, true>(p, s, (int)M);
 }

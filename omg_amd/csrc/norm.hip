@@ -18,6 +18,8 @@ struct GnP {
   int B, HW, G, cpg, nvec, tpp, vpt, pr, nchunk, ppc, b0;
   float eps; const char* gamma; const char* beta; int silu;
   float* ws; char* Y;
+  char* Q; unsigned char* S; long P;       // MX8 output: e4m3 bytes [B*HW][Cq] + scale bytes [(Cq/128)][P][4], P = B*HW
+  int Cq;                                  // C rounded up to a multiple of 128: the pad channels are written as zeros (scale byte 0)
 };
 
 template <typename T>
@@ -89,7 +91,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnP p) {
   }
 }
 
-template <typename T>
+// MX8 = true: the consumer is the MX-fp8 convolution (gemm_mx8.hip).  y is rounded to T exactly as the 16-bit kernel stores it,
+// then quantised per 32 consecutive channels (4 neighbouring lanes: two DPP exchanges for the amax) with the rule of
+// quant_mx8_kernel; the scale bytes go to S[c / 128][pixel][(c / 32) % 4] — the conv kernel fetches one dword per (output row,
+// tap, 128-channel stage) with a per-lane LDS-DMA.
+template <typename T, bool MX8 = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
   __shared__ float mean_s[64], rstd_s[64];
   const int tid = threadIdx.x;
@@ -150,7 +156,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
               if (p.silu) y = silu_fast(y);
               f[u][e] = y;
             }
-            store8<T>(p.Y + (((long)b * p.HW + px) * C + vec * 8) * (long)sizeof(T), f[u]);
+            if constexpr (!MX8) store8<T>(p.Y + (((long)b * p.HW + px) * C + vec * 8) * (long)sizeof(T), f[u]);
+          }
+        }
+        if constexpr (MX8) {
+          // all four lanes of a 32-channel block share px (same prow) and take the same branches: the exchanges are safe
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int px = pix + u * p.pr;
+            const bool ok = px < pix1;
+            float r[8];
+            {
+              const u32x4 pk = pack8<T>(f[u]);      // the value the 16-bit path would have stored
+              unpack8<T>(pk, r);
+            }
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = __builtin_fmaxf(amax, __builtin_fabsf(r[e]));
+            if (!ok) amax = 0.f;
+            amax = __builtin_fmaxf(amax, __shfl_xor(amax, 1));
+            amax = __builtin_fmaxf(amax, __shfl_xor(amax, 2));
+            const unsigned be = mx8_scale_exp(amax);
+            const float inv = mx8_inv_scale(be);
+            if (ok) {
+              const long gp = (long)b * p.HW + px;
+              u32x2 o = {mx8_pack4(r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv), mx8_pack4(r[4] * inv, r[5] * inv, r[6] * inv, r[7] * inv)};
+              *(u32x2*)(p.Q + gp * p.Cq + vec * 8) = o;
+              if ((vec & 3) == 0) p.S[(((long)(vec >> 4) * p.P + gp) << 2) + ((vec >> 2) & 3)] = (unsigned char)be;
+              const int cpad = C + vec * 8;      // the first (Cq - C) / 8 lanes of the pixel also clear its pad channels
+              if (cpad < p.Cq) {
+                *(u32x2*)(p.Q + gp * p.Cq + cpad) = u32x2{0u, 0u};
+                if ((cpad & 31) == 0) p.S[(((long)(cpad >> 7) * p.P + gp) << 2) + ((cpad >> 5) & 3)] = 0;
+              }
+            }
           }
         }
       }
@@ -309,11 +347,14 @@ extern "C" int64_t omg_groupnorm_ws_floats(int B, int groups, int HW) {
   return (int64_t)B * GN_MAX_CHUNKS * groups * 2;
 }
 
-extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
-                             float eps, const void* gamma, const void* beta, int silu, float* workspace, void* Y,
-                             void* stream) {
-  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16 || dtype == OMG_F32, "omg_groupnorm: dtype");
-  OMG_REQUIRE(X1 && gamma && beta && workspace && Y && (C2 == 0 || X2), "omg_groupnorm: null operand");
+namespace {
+int gn_run(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
+           float eps, const void* gamma, const void* beta, int silu, float* workspace, void* Y, void* Q, void* S,
+           void* stream) {
+  const bool mx8 = Q != nullptr;
+  OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16 || (dtype == OMG_F32 && !mx8), "omg_groupnorm: dtype");
+  OMG_REQUIRE(X1 && gamma && beta && workspace && (Y || mx8) && (C2 == 0 || X2), "omg_groupnorm: null operand");
+  if (mx8) OMG_REQUIRE(S != nullptr && (C1 + C2) % 32 == 0, "omg_groupnorm_mx8: scales, C % 32 == 0");
   const int C = C1 + C2;
   OMG_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && groups <= 64 && groups > 0, "omg_groupnorm: channels/groups");
   OMG_REQUIRE(C / 8 <= 512, "omg_groupnorm: C <= 4096");
@@ -334,6 +375,7 @@ extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, 
   p.nchunk = nchunk;
   p.eps = eps; p.gamma = (const char*)gamma; p.beta = (const char*)beta; p.silu = silu;
   p.ws = workspace; p.Y = (char*)Y;
+  p.Q = (char*)Q; p.S = (unsigned char*)S; p.P = (long)B * HW; p.Cq = (C + 127) / 128 * 128;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)2 * p.pr * C * sizeof(float);
   // one pair of launches for the whole batch.  Tried and rejected (round 2): statistics + apply on groups of samples sized to the
@@ -345,16 +387,33 @@ extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, 
     dim3 grid(nchunk, nb);
     if (dtype == OMG_F16) {
       OMG_LAUNCH(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
-      OMG_LAUNCH(gn_apply_kernel<f16>, grid, dim3(256), 0, s, p);
+      if (mx8) OMG_LAUNCH((gn_apply_kernel<f16, true>), grid, dim3(256), 0, s, p);
+      else OMG_LAUNCH((gn_apply_kernel<f16, false>), grid, dim3(256), 0, s, p);
     } else if (dtype == OMG_BF16) {
       OMG_LAUNCH(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
-      OMG_LAUNCH(gn_apply_kernel<bf16>, grid, dim3(256), 0, s, p);
+      if (mx8) OMG_LAUNCH((gn_apply_kernel<bf16, true>), grid, dim3(256), 0, s, p);
+      else OMG_LAUNCH((gn_apply_kernel<bf16, false>), grid, dim3(256), 0, s, p);
     } else {          // fp32 storage: the up-blocks of the upcast VAE decode (lora_pipeline.py:639-652)
       OMG_LAUNCH(gn_stats_kernel<float>, grid, dim3(256), lds, s, p);
-      OMG_LAUNCH(gn_apply_kernel<float>, grid, dim3(256), 0, s, p);
+      OMG_LAUNCH((gn_apply_kernel<float, false>), grid, dim3(256), 0, s, p);
     }
   }
   return omg_check_launch("groupnorm");
+}
+}  // namespace
+
+extern "C" int omg_groupnorm(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
+                             float eps, const void* gamma, const void* beta, int silu, float* workspace, void* Y,
+                             void* stream) {
+  OMG_REQUIRE(Y != nullptr, "omg_groupnorm: null output");
+  return gn_run(dtype, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, silu, workspace, Y, nullptr, nullptr, stream);
+}
+
+extern "C" int omg_groupnorm_mx8(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int HW, int groups,
+                                 float eps, const void* gamma, const void* beta, int silu, float* workspace, void* Q,
+                                 void* scales, void* stream) {
+  OMG_REQUIRE(Q != nullptr && scales != nullptr, "omg_groupnorm_mx8: null output");
+  return gn_run(dtype, X1, C1, X2, C2, B, HW, groups, eps, gamma, beta, silu, workspace, nullptr, Q, scales, stream);
 }
 
 extern "C" int omg_layernorm(int dtype, const void* X, int64_t ldx, int M, int C, float eps, const void* gamma,

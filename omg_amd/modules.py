@@ -207,14 +207,34 @@ class Conv2d(_Packed):
         self.cin, self.cout, self.ksize, self.stride = cin, cout, ksize, stride
         self.weight = nn.Parameter(torch.empty(cout, cin, ksize, ksize, dtype=dtype, device=device), requires_grad=False)
         self.bias = nn.Parameter(torch.empty(cout, dtype=dtype, device=device), requires_grad=False)
+        self.mx8 = False          # run on the block-scaled fp8 MFMA when fed an MX-fp8 feature map (UNet.set_conv_precision)
 
     def packed_weight(self) -> torch.Tensor:
         if "w" not in self._packed:
             self._packed["w"] = ops.pack_conv_weight(self.weight.data)
         return self._packed["w"]
 
+    def mx8_ok(self) -> bool:
+        """MX-fp8 eligibility: 3x3 / stride 1 on a 16-bit weight whose input channels are whole 32-element MX blocks."""
+        return self.mx8 and self.ksize == 3 and self.stride == 1 and self.cin % 32 == 0 and self.weight.dtype != torch.float32
+
+    def mx8_weight(self) -> "ops.Mx8Tensor":
+        if "wq" not in self._packed:          # quantised once from the packed 16-bit weight; Cin padded with zeros to whole 128-wide K stages
+            w = self.packed_weight()
+            cq = (self.cin + 127) // 128 * 128
+            if cq != self.cin:
+                wp = torch.zeros((self.cout, 9, cq), dtype=w.dtype, device=w.device)
+                wp[:, :, :self.cin] = w.view(self.cout, 9, self.cin)
+                w = wp.view(self.cout, 9 * cq)
+            self._packed["wq"] = ops.quant_mx8(w)
+        return self._packed["wq"]
+
     def forward(self, x: torch.Tensor, *, x2: Optional[torch.Tensor] = None, upsample: bool = False,
                 group_bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if isinstance(x, ops.Mx8Map):                   # GroupNorm wrote the operand format of the fp8 MFMA directly
+            if not self.mx8_ok() or x2 is not None or upsample:
+                raise L.OmgHipError("an MX-fp8 feature map can only feed a 3x3 / stride 1 convolution in MX-fp8 mode")
+            return ops.conv2d_mx8(x, self.mx8_weight(), bias=self.bias, group_bias=group_bias, residual=residual)
         if self.weight.dtype == torch.float32:          # fp32 storage (the up blocks of the upcast VAE decode): f32-input MFMA kernel
             if x2 is not None or group_bias is not None or self.stride != 1:
                 raise L.OmgHipError("the fp32 convolution supports stride 1 without concat / per-sample bias (all the VAE decoder needs)")
@@ -230,7 +250,10 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
         self.bias = nn.Parameter(torch.empty(channels, dtype=dtype, device=device), requires_grad=False)
 
-    def forward(self, x: torch.Tensor, *, x2: Optional[torch.Tensor] = None, silu: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, *, x2: Optional[torch.Tensor] = None, silu: bool = False, mx8: bool = False):
+        """``mx8=True``: the result as an :class:`omg_amd.ops.Mx8Map` for an MX-fp8 convolution (never stored in 16 bits)."""
+        if mx8:
+            return ops.groupnorm_mx8(x, self.weight, self.bias, self.groups, self.eps, silu=silu, x2=x2)
         return ops.groupnorm(x, self.weight, self.bias, self.groups, self.eps, silu=silu, x2=x2)
 
 

@@ -277,6 +277,76 @@ def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, up
     return y
 
 
+class Mx8Map:
+    """An MX-fp8 NHWC feature map: ``q`` uint8 [B, H, W, Cq] (OCP e4m3), ``scales`` int32 [Cq/128, B*H*W] (byte j of a dword = the
+    E8M0 scale of channels 128 k + 32 j .. + 31 of that pixel) — what omg_groupnorm_mx8 writes and omg_conv2d_mx8 reads.
+    Cq = the channel count rounded up to a multiple of 128; pad channels are zeros."""
+
+    __slots__ = ("q", "scales", "shape", "dtype")
+
+    def __init__(self, q: torch.Tensor, scales: torch.Tensor, dtype: torch.dtype):
+        self.q, self.scales, self.shape, self.dtype = q, scales, tuple(q.shape), dtype
+
+    @property
+    def device(self):
+        return self.q.device
+
+
+def groupnorm_mx8(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
+                  silu: bool = False, x2: Optional[torch.Tensor] = None) -> Mx8Map:
+    """NHWC GroupNorm (+SiLU) of [x1 | x2] straight into MX-fp8 (the input of an MX-fp8 convolution): equal to quantising
+    :func:`groupnorm`'s 16-bit output, which is never stored."""
+    _dev(x1)
+    assert x1.is_contiguous() and x1.dim() == 4
+    B, H, W, C1 = x1.shape
+    C2 = 0
+    if x2 is not None:
+        assert x2.is_contiguous() and x2.shape[:3] == x1.shape[:3]
+        C2 = x2.shape[-1]
+    Cc = C1 + C2
+    if Cc % 32 != 0:
+        raise L.OmgHipError("MX-fp8 feature maps need C % 32 == 0")
+    Cq = (Cc + 127) // 128 * 128
+    out = Mx8Map(torch.empty((B, H, W, Cq), dtype=torch.uint8, device=x1.device),
+                 torch.empty((Cq // 128, B * H * W), dtype=torch.int32, device=x1.device), x1.dtype)
+    ws = _gn_workspace(x1.device, B, groups, H * W)
+    assert gamma.dtype == x1.dtype and beta.dtype == x1.dtype
+    L.check(L.lib().omg_groupnorm_mx8(_dt(x1), x1.data_ptr(), C1, _p(x2), C2, B, H * W, groups, eps, gamma.data_ptr(), beta.data_ptr(),
+                                      int(silu), ws.data_ptr(), out.q.data_ptr(), out.scales.data_ptr(), _stream()), "omg_groupnorm_mx8")
+    return out
+
+
+def conv2d_mx8(x: Mx8Map, w: "Mx8Tensor", *, bias: Optional[torch.Tensor] = None, group_bias: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, out_scale: float = 1.0, act: int = L.ACT_NONE) -> torch.Tensor:
+    """3x3 / stride 1 / pad 1 convolution on the block-scaled fp8 MFMA (omg_conv2d_mx8).  ``w`` = quant_mx8 of the packed
+    [Cout, 9*Cin] weight (pack_conv_weight); output, bias, per-sample bias and residual in ``x.dtype``."""
+    _dev(x.q)
+    B, H, W, Cin = x.shape
+    Cout = w.rows
+    assert w.K == 9 * Cin
+    y = torch.empty((B, H, W, Cout), dtype=x.dtype, device=x.device)
+    a = L.Conv2dMx8Args()
+    a.dtype = _DT[x.dtype]
+    a.B, a.H, a.W, a.Cin, a.Cout = B, H, W, Cin, Cout
+    a.X, a.x_scale, a.Wq, a.w_scale = x.q.data_ptr(), x.scales.data_ptr(), w.q.data_ptr(), w.scales.data_ptr()
+    a.sw_ld, a.act = w.scales.stride(0), act
+    a.bias = _p(bias)
+    if group_bias is not None:
+        a.group_bias, a.ldgb = group_bias.data_ptr(), group_bias.stride(0)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == y.shape and residual.dtype == y.dtype
+        a.residual = residual.data_ptr()
+    a.out_scale = out_scale
+    a.Y = y.data_ptr()
+    if _PROF is not None:
+        t0 = _PROF.begin()
+        L.check(L.lib().omg_conv2d_mx8(C.byref(a), _stream()), "omg_conv2d_mx8")
+        _PROF.end("gemm_mx8", 2.0 * B * H * W * Cout * 9 * Cin, t0, ("conv_mx8", B * H * W, Cout, 9 * Cin, 0, 1, 0))
+        return y
+    L.check(L.lib().omg_conv2d_mx8(C.byref(a), _stream()), "omg_conv2d_mx8")
+    return y
+
+
 def conv2d_f32(x: torch.Tensor, w: torch.Tensor, ksize: int, *, upsample: bool = False, bias: Optional[torch.Tensor] = None,
                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 NHWC convolution on the f32-input MFMA (omg_conv2d_f32): the up blocks of the upcast VAE decode.

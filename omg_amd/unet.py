@@ -95,10 +95,11 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, ctx: _Ctx, x2=None):
         """x (B,H,W,C1) [, x2 (B,H,W,C2): the skip tensor, consumed as channel-concat without copying]."""
-        h = self.norm1(x, x2=x2, silu=True)
+        # MX-fp8 mode: the two GroupNorms write their convolution's operand format directly (bytes + per-pixel block scales)
+        h = self.norm1(x, x2=x2, silu=True, mx8=self.conv1.mx8_ok())
         tproj = self.time_emb_proj(ctx.silu_emb)                     # (B, Cout)
         h = self.conv1(h, group_bias=tproj)
-        h = self.norm2(h, silu=True)
+        h = self.norm2(h, silu=True, mx8=self.conv2.mx8_ok())
         if self.conv_shortcut is not None:
             sc = self.conv_shortcut(x, x2=x2)
         else:
@@ -375,6 +376,18 @@ class UNet2DConditionModel(nn.Module):
                            (".attentions." in name and ".attn1." in name)
                 m.mx8 = on and in_block and m.in_features % 128 == 0
         self.linear_precision = mode
+
+    def set_conv_precision(self, mode: str = "fp16") -> None:
+        """``"mx8"``: conv1 / conv2 of every ResnetBlock2D run as MX-fp8 implicit GEMMs (omg_conv2d_mx8) on the feature map their
+        GroupNorm + SiLU writes in MX-fp8 (omg_groupnorm_mx8; 320- and 960-channel maps padded with zero channels to 384 / 1024).  Kept in 16 bits: conv_in / conv_out, the down / up-sampling
+        convolutions and the 1x1 shortcuts (their inputs are residual-stream tensors no norm has bounded), GroupNorm statistics,
+        the time-embedding projection added as per-sample bias, the skip connection added in the epilogue."""
+        if mode not in ("fp16", "mx8"):
+            raise ValueError(mode)
+        for m in self.modules():
+            if isinstance(m, ResnetBlock2D):
+                m.conv1.mx8 = m.conv2.mx8 = mode == "mx8"
+        self.conv_precision = mode
 
     # ------------------------------------------------------------------ LoRA selection
     def set_lora_state(self, state: Optional[LoraState]) -> None:

@@ -28,21 +28,21 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     for name in declared:
         assert re.search(rf"\bT {name}\b", nm), f"{name} is not a defined text symbol"
-    assert lib.omg_abi_version() == 4
+    assert lib.omg_abi_version() == 5
 
 
 def test_struct_sizes_match_the_header():
     """ctypes mirrors must have the size the C compiler gives the structs."""
     import ctypes
     from omg_amd import _lib
-    code = '#include <stdio.h>\n#include "omg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",sizeof(omg_gemm_args),sizeof(omg_conv2d_args),sizeof(omg_attn_args),sizeof(omg_step_args),sizeof(omg_gemm_mx8_args));return 0;}'
+    code = '#include <stdio.h>\n#include "omg_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",sizeof(omg_gemm_args),sizeof(omg_conv2d_args),sizeof(omg_attn_args),sizeof(omg_step_args),sizeof(omg_gemm_mx8_args),sizeof(omg_conv2d_mx8_args),sizeof(omg_conv2d_f32_args));return 0;}'
     exe = os.path.join(ROOT, "tests", "_sizes.out")
     subprocess.run(["gcc", "-x", "c", "-I", os.path.join(ROOT, "include"), "-o", exe, "-"], input=code.encode(), check=True)
     try:
         out = subprocess.check_output([exe], text=True).split()
     finally:
         os.remove(exe)
-    got = [ctypes.sizeof(c) for c in (_lib.GemmArgs, _lib.Conv2dArgs, _lib.AttnArgs, _lib.StepArgs, _lib.GemmMx8Args)]
+    got = [ctypes.sizeof(c) for c in (_lib.GemmArgs, _lib.Conv2dArgs, _lib.AttnArgs, _lib.StepArgs, _lib.GemmMx8Args, _lib.Conv2dMx8Args, _lib.Conv2dF32Args)]
     assert got == [int(v) for v in out]
 
 
