@@ -52,7 +52,7 @@ OMG_DEV f32x16 mfma_mx8(i32x8 a, i32x8 b, f32x16 c, int sa, int sb, int ks) {
 // scales are stored per pixel, SA[C/128][B*H*W] dwords (omg_groupnorm_mx8 writes them): every wave fetches the dwords of 64 of
 // the tile's rows with ONE 4-byte-per-lane LDS-DMA per stage at the tap-shifted pixel (out of range: byte 0 = 2^-127, times
 // zeros).  Weights [Cout][9 C] and their scales are those of the Linear path (omg_quant_mx8 of the packed conv weight).
-template <typename T, int D1, bool CONV = false>
+template <typename T, int D1, bool CONV = false, bool XE = true>
 __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
   constexpr int MT = 4, NT = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,7 +275,9 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
 #undef MX_DMA
 #undef MX_INSIDE
 #undef MX_PREP
-  epilogue_direct<T, MT, NT>(p, acc, lane, m0 + wm * 128, n0 + wn * 128, m_end, gb_epi);
+  // Transposed streaming epilogue (gemm_epilogue.h, XE): the 8 KB per wave it needs are taken from the stage buffer the LAST
+  // stage does not use — released for every wave by that stage's barrier, never read or filled again.
+  epilogue_direct<T, MT, NT, XE>(p, acc, lane, m0 + wm * 128, n0 + wn * 128, m_end, gb_epi, smem + (nk & 1) * MX_STAGE + w * 8192);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const char* x, long ldx,
 }
 
 int g_mx_d1 = 12;      // measured best of 8 / 12 / 16 on the UNet's shapes (profiles/r02_mx8_bench.log)
+int g_mx_dbg = 0;      // 64: register-direct epilogue instead of the transposed streaming one (tools / A-B only)
 
 template <typename T, bool CONV = false>
 int launch_mx8(GemmP p, hipStream_t s, int mrows) {
@@ -333,22 +336,24 @@ int launch_mx8(GemmP p, hipStream_t s, int mrows) {
   p.tiles_n = (p.N + 255) / 256;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-#define MX_LAUNCH(D1_)                                                                                     \
+  p.dbg = g_mx_dbg;
+#define MX_LAUNCH(D1_, XE_)                                                                                \
   do {                                                                                                     \
     static bool attr = false;                                                                              \
-    if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel<T, D1_, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
-    OMG_LAUNCH((gemm_mx8_kernel<T, D1_, CONV>), dim3(grid), dim3(256), lds, s, p);                         \
+    if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel<T, D1_, CONV, XE_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
+    OMG_LAUNCH((gemm_mx8_kernel<T, D1_, CONV, XE_>), dim3(grid), dim3(256), lds, s, p);                    \
   } while (0)
-  if (g_mx_d1 >= 16) MX_LAUNCH(16);
-  else if (g_mx_d1 >= 12) MX_LAUNCH(12);
-  else MX_LAUNCH(8);
+  if (g_mx_dbg & 64) MX_LAUNCH(12, false);
+  else if (g_mx_d1 >= 16) MX_LAUNCH(16, true);
+  else if (g_mx_d1 >= 12) MX_LAUNCH(12, true);
+  else MX_LAUNCH(8, true);
 #undef MX_LAUNCH
   return omg_check_launch("gemm_mx8");
 }
 
 }  // namespace
 
-extern "C" void omg_debug_set_mx8_split(int d1) { g_mx_d1 = d1; }
+extern "C" void omg_debug_set_mx8_split(int d1) { g_mx_d1 = d1 & 0xff; g_mx_dbg = d1 >> 8; }
 
 extern "C" int omg_quant_mx8(int dtype, const void* x, long ldx, int M, int K, void* q, long ldq, void* scales, int s_ld, void* stream) {
   OMG_REQUIRE(dtype == OMG_F16 || dtype == OMG_BF16, "omg_quant_mx8: dtype");
