@@ -122,6 +122,10 @@ typedef struct {
   int32_t act;                /* OMG_ACT_NONE | OMG_ACT_SILU | OMG_ACT_GEGLU          */
   float out_scale;
   void* C; int64_t ldc;
+  /* c_scale != NULL (GEGLU only, N % 256 == 0): the result is written as the NEXT omg_gemm_mx8's A operand instead of 16 bits —
+   * C = e4m3 bytes [M][N/2] (ldc in bytes, % 16), c_scale = uint32 [N/2/128][sc_ld] — bit-identical to omg_quant_mx8 of the
+   * 16-bit result (FeedForward: GEGLU -> Linear, diffusers attention.py). */
+  void* c_scale; int32_t sc_ld;
 } omg_gemm_mx8_args;
 
 int omg_gemm_mx8(const omg_gemm_mx8_args* a, void* stream);

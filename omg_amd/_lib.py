@@ -44,6 +44,7 @@ class GemmMx8Args(C.Structure):
         ("bias", c_vp), ("residual", c_vp), ("ldr", c_i64),
         ("act", c_i32), ("out_scale", c_f32),
         ("C", c_vp), ("ldc", c_i64),
+        ("c_scale", c_vp), ("sc_ld", c_i32),
     ]
 
 

@@ -30,6 +30,9 @@ struct GemmP {
   const char* SA; const char* SW;
   int sa_ld, sw_ld;
   long sw_adapter_stride;
+  // MX-fp8 OUTPUT (GEGLU epilogue of gemm_mx8.hip only): C is then the e4m3 byte matrix (ldc in bytes) and QS its stage-major
+  // scale dwords [n_out / 128][qs_ld] — the operand format of the next omg_gemm_mx8
+  char* QS; int qs_ld;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -186,6 +189,34 @@ OMG_DEV void xe_flush(const GemmP& p, const EpiCtx<4>& cx, int i, int col0) {
     const u32x4 x = *(const u32x4*)(cx.xl + rr * ROWB + ((c ^ sw) << 4));
     if (u * RPI >= 16) d[u] = u32x4{x[2], x[3], x[0], x[1]}; else d[u] = x;     // rows >= 16 hold their halves exchanged
   }
+  if constexpr (ROWB == 128) {
+    if (p.QS != nullptr) {
+      // MX-fp8 output: the lane's 8 columns are a quarter of a 32-wide block (pieces 0-3: block 0 of the wave's 64 columns,
+      // 4-7: block 1).  The 16-bit values just packed are what the unfused path would have stored and omg_quant_mx8 read.
+      const __amdgpu_buffer_rsrc_t rsQ = epi_rsrc(p.QS, (long)(cx.n_out >> 7) * p.qs_ld * 4);
+      const int sbase = ((col0 >> 7) * p.qs_ld) * 4 + ((col0 >> 5) & 3);          // the wave's first block inside its stage dword
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int gm = cx.wm0 + i * 32 + u * RPI + rq;
+        float f[8];
+        unpack8<T>(d[u], f);
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = __builtin_fmaxf(amax, __builtin_fabsf(f[e]));
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 1));
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 2));
+        const unsigned be = mx8_scale_exp(amax);
+        const float inv = mx8_inv_scale(be);
+        const u32x2 o = {mx8_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv), mx8_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv)};
+        const bool ok = gm < cx.m_end && col_ok;
+        __builtin_amdgcn_raw_buffer_store_b64(o, cx.rsC, ok ? gm * (int)p.ldc + col0 + 8 * c : EPI_OOB, 0, 0);
+        const unsigned both = be | (__shfl_down(be, 4) << 8);                     // lane c = 0: blocks 0 and 1 of the wave's row
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)both, rsQ, (ok && c == 0) ? sbase + gm * 4 : EPI_OOB, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+      return;
+    }
+  }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int gm = cx.wm0 + i * 32 + u * RPI + rq;
@@ -293,7 +324,7 @@ OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, in
   const int n_out = geglu ? p.N / 2 : p.N;
   EpiCtx<NT> cx;
   cx.hi = lane >> 5; cx.l31 = lane & 31; cx.wm0 = wm0; cx.m_end = m_end;
-  cx.rsC = epi_rsrc(p.C, ((long)(p.M - 1) * p.ldc + n_out) * 2);
+  cx.rsC = epi_rsrc(p.C, p.QS != nullptr ? (long)(p.M - 1) * p.ldc + n_out : ((long)(p.M - 1) * p.ldc + n_out) * 2);
   cx.rsR = epi_rsrc(p.residual, ((long)(p.M - 1) * p.ldr + p.N) * 2);
   cx.rsG = epi_rsrc(has_gb ? p.group_bias : nullptr, 0x7effff00L);
   // the buffer bound only protects the end of the matrix, not the end of a row: per-unit column predicate, as an

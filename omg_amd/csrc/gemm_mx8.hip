@@ -375,13 +375,14 @@ extern "C" int omg_gemm_mx8(const omg_gemm_mx8_args* a, void* stream) {
   if (a->M == 0) return OMG_OK;
   OMG_REQUIRE(a->K % 128 == 0 && a->N % 8 == 0, "omg_gemm_mx8: K must be a multiple of 128, N of 8");
   OMG_REQUIRE(a->lda % 16 == 0 && a->ldw % 16 == 0 && a->ldc % 8 == 0, "omg_gemm_mx8: lda, ldw multiples of 16; ldc of 8");
+  const long c_elt = a->c_scale != nullptr ? 1 : 2;
   OMG_REQUIRE(a->A && a->W && a->C && a->a_scale && a->w_scale, "omg_gemm_mx8: null operand");
   OMG_REQUIRE(a->sa_ld >= a->M && a->sa_ld % 4 == 0 && a->sw_ld % 4 == 0, "omg_gemm_mx8: scale row counts");
   OMG_REQUIRE(a->groups >= 1 && (long)a->groups * a->rows_per_group == a->M, "omg_gemm_mx8: M != groups*rows_per_group");
   if (a->act == OMG_ACT_GEGLU) OMG_REQUIRE(a->N % 64 == 0 && !a->residual, "omg_gemm_mx8: GEGLU needs N % 64 == 0, no residual");
   if (a->residual) OMG_REQUIRE(a->ldr % 8 == 0, "omg_gemm_mx8: ldr");
   const long lim = 0x7fff0000L;
-  OMG_REQUIRE((long)a->M * a->lda < lim && (long)a->N * a->ldw < lim && (long)a->M * (a->ldc > a->ldr ? a->ldc : a->ldr) * 2 < lim,
+  OMG_REQUIRE((long)a->M * a->lda < lim && (long)a->N * a->ldw < lim && (long)a->M * a->ldc * c_elt < lim && (long)a->M * a->ldr * 2 < lim,
               "omg_gemm_mx8: an operand exceeds the 2 GiB buffer-descriptor range");
   GemmP p{};
   p.M = a->M; p.N = a->N; p.K = a->K;
@@ -395,6 +396,11 @@ extern "C" int omg_gemm_mx8(const omg_gemm_mx8_args* a, void* stream) {
   OMG_REQUIRE(a->sw_ld >= (a->w_adapter_stride != 0 ? 0 : a->N), "omg_gemm_mx8: sw_ld < N");
   p.bias = (const char*)a->bias; p.residual = (const char*)a->residual; p.ldr = a->ldr;
   p.act = a->act; p.out_scale = a->out_scale; p.C = (char*)a->C; p.ldc = a->ldc;
+  if (a->c_scale != nullptr) {
+    OMG_REQUIRE(a->act == OMG_ACT_GEGLU && a->N % 256 == 0 && a->ldc % 16 == 0 && a->sc_ld >= a->M && a->sc_ld % 4 == 0 && !(g_mx_dbg & 64),
+                "omg_gemm_mx8: MX-fp8 output needs the GEGLU epilogue, N % 256 == 0, ldc % 16 == 0, sc_ld >= M");
+    p.QS = (char*)a->c_scale; p.qs_ld = a->sc_ld;
+  }
   const int mrows = per_group ? a->rows_per_group : a->M;
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == OMG_F16 ? launch_mx8<f16>(p, s, mrows) : launch_mx8<bf16>(p, s, mrows);

@@ -162,26 +162,30 @@ class GEGLU(_Packed):
     def invalidate_packed(self):
         super().invalidate_packed()
 
-    def _forward_mx8(self, x) -> torch.Tensor:
+    def _forward_mx8(self, x, out_mx8: bool = False):
         xq = x if isinstance(x, ops.Mx8Tensor) else ops.quant_mx8(x)
         shp = xq.shape
         pk = self._packed_w()
         st = self.proj.lora_state
         dt = self.proj.weight.dtype
+        out_mx8 = out_mx8 and self.proj.out_features % 256 == 0
         if st is not None and st.merged and "w_slots" in pk:
             if "mx8_slots" not in pk:
                 pk["mx8_slots"] = ops.quant_mx8(pk["w_slots"].reshape(-1, self.proj.in_features))
             y = ops.gemm_mx8(xq, pk["mx8_slots"], out_dtype=dt, bias=pk["b"], act=L.ACT_GEGLU, groups=st.groups,
-                             w_group_adapter=st.group_adapter, n_per_adapter=self.proj.out_features)
+                             w_group_adapter=st.group_adapter, n_per_adapter=self.proj.out_features, out_mx8=out_mx8)
         else:
             if "mx8_w" not in pk:
                 pk["mx8_w"] = ops.quant_mx8(pk["w"])
-            y = ops.gemm_mx8(xq, pk["mx8_w"], out_dtype=dt, bias=pk["b"], act=L.ACT_GEGLU)
+            y = ops.gemm_mx8(xq, pk["mx8_w"], out_dtype=dt, bias=pk["b"], act=L.ACT_GEGLU, out_mx8=out_mx8)
+        if isinstance(y, ops.Mx8Tensor):
+            return y
         return y.view(*shp[:-1], y.shape[-1])
 
-    def forward(self, x) -> torch.Tensor:
+    def forward(self, x, out_mx8: bool = False):
+        """``out_mx8``: the consumer is an MX-fp8 Linear — hand it its operand (bytes + block scales) straight from the epilogue."""
         if isinstance(x, ops.Mx8Tensor) or (self.proj.mx8 and self.proj._mx8_ok()):
-            return self._forward_mx8(x)
+            return self._forward_mx8(x, out_mx8)
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         pk = self._packed_w()

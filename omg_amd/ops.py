@@ -199,8 +199,11 @@ def quant_mx8(x: torch.Tensor, out: Optional[Mx8Tensor] = None) -> Mx8Tensor:
 def gemm_mx8(a: Mx8Tensor, w: Mx8Tensor, *, out_dtype: torch.dtype = torch.float16, bias: Optional[torch.Tensor] = None,
              residual: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out: Optional[torch.Tensor] = None,
              out_scale: float = 1.0, groups: int = 1, w_group_adapter: Optional[torch.Tensor] = None,
-             n_per_adapter: Optional[int] = None) -> torch.Tensor:
+             n_per_adapter: Optional[int] = None, out_mx8: bool = False):
     """``out[M, N_out] = epi(dequant(a) @ dequant(w)^T)`` on the block-scaled fp8 MFMA (omg_gemm_mx8).
+
+    ``out_mx8`` (GEGLU only, N % 256 == 0): return the result as an :class:`Mx8Tensor` — the next MX-fp8 Linear's operand,
+    quantised in the epilogue, bit-identical to ``quant_mx8`` of the 16-bit result, which is never stored.
 
     With ``w_group_adapter`` (int32 [groups]) ``w`` holds ``n_adapters * n_per_adapter`` rows — the per-sample weight slots of
     the merged-LoRA mode stacked along the rows — and group g uses rows ``[id_g * n_per_adapter, (id_g + 1) * n_per_adapter)``."""
@@ -208,11 +211,17 @@ def gemm_mx8(a: Mx8Tensor, w: Mx8Tensor, *, out_dtype: torch.dtype = torch.float
     assert w.K == K
     N = n_per_adapter if w_group_adapter is not None else w.rows
     n_out = N // 2 if act == L.ACT_GEGLU else N
-    if out is None:
+    oq = None
+    if out_mx8:
+        assert out is None and act == L.ACT_GEGLU and N % 256 == 0
+        oq = Mx8Tensor(torch.empty((M, n_out), dtype=torch.uint8, device=a.q.device),
+                       torch.empty((n_out // 128, (M + 3) // 4 * 4), dtype=torch.int32, device=a.q.device), tuple(a.shape[:-1]) + (n_out,))
+        out = oq.q
+    elif out is None:
         out = torch.empty((M, n_out), dtype=out_dtype, device=a.q.device)
     assert out.stride(1) == 1 and out.shape == (M, n_out)
     g = L.GemmMx8Args()
-    g.dtype = _dt(out)
+    g.dtype = _DT[out_dtype] if out_mx8 else _dt(out)
     g.M, g.N, g.K = M, N, K
     g.A, g.lda, g.a_scale, g.sa_ld = a.q.data_ptr(), a.q.stride(0), a.scales.data_ptr(), a.scales.stride(0)
     g.W, g.ldw, g.w_scale, g.sw_ld = w.q.data_ptr(), w.q.stride(0), w.scales.data_ptr(), w.scales.stride(0)
@@ -226,13 +235,15 @@ def gemm_mx8(a: Mx8Tensor, w: Mx8Tensor, *, out_dtype: torch.dtype = torch.float
         g.residual, g.ldr = residual.data_ptr(), residual.stride(0)
     g.act, g.out_scale = act, out_scale
     g.C, g.ldc = out.data_ptr(), out.stride(0)
+    if oq is not None:
+        g.c_scale, g.sc_ld = oq.scales.data_ptr(), oq.scales.stride(0)
     if _PROF is not None:
         t0 = _PROF.begin()
         L.check(L.lib().omg_gemm_mx8(C.byref(g), _stream()), "omg_gemm_mx8")
         _PROF.end("gemm_mx8", 2.0 * M * N * K, t0, ("mx8", M, N, K, 0, groups if w_group_adapter is not None else 1, act))
-        return out
+        return oq if oq is not None else out
     L.check(L.lib().omg_gemm_mx8(C.byref(g), _stream()), "omg_gemm_mx8")
-    return out
+    return oq if oq is not None else out
 
 
 def conv2d(x1: torch.Tensor, w: torch.Tensor, ksize: int, *, stride: int = 1, upsample: bool = False,

@@ -115,7 +115,8 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * 4, dtype, device), nn.Identity(), Linear(dim * 4, dim, dtype=dtype, device=device)])
 
     def forward(self, x, residual=None):
-        return self.net[2](self.net[0](x), residual=residual)
+        # MX-fp8 mode: the GEGLU epilogue quantises for the output Linear (the 16-bit intermediate [rows, 4 dim] is never stored)
+        return self.net[2](self.net[0](x, out_mx8=self.net[2].mx8 and self.net[2]._mx8_ok()), residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):

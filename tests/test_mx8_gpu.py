@@ -328,3 +328,24 @@ def test_conv2d_mx8_at_bench_size_on_sampled_pixels(dev):
         err = (out.reshape(M, Cout)[pix.to(dev)].float().cpu() - ref).abs()
         assert (err <= 3e-3 + 2e-3 * ref.abs()).all(), (B, H, W, C, Cout, err.max().item())
         print(f"conv_mx8 {B}x{H}x{W}x{C}->{Cout}: {len(pix)} pixels, max |d| vs dequantised fp32 {err.max().item():.2e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,slots", [(512, 512, 256, False), (300, 1024, 384, False), (2048, 2560, 640, True)])
+def test_geglu_epilogue_mx8_output_equals_quantising_the_16bit_result(dev, dtype, M, N, K, slots):
+    """omg_gemm_mx8 with c_scale (FeedForward: GEGLU feeding an MX-fp8 Linear): bytes and scale dwords must equal omg_quant_mx8
+    of the 16-bit GEGLU output bit for bit — ragged rows, two column tiles, per-sample weight slots."""
+    a = gen((M, K), 41, dtype=dtype).to(dev)
+    nsl = 3 if slots else 1
+    w = gen((nsl * N, K), 42, scale=K ** -0.5, dtype=dtype).to(dev)
+    b = gen((N,), 43, dtype=dtype).to(dev)
+    ta, tw = ops.quant_mx8(a), ops.quant_mx8(w)
+    kw = dict(bias=b, act=L.ACT_GEGLU, out_dtype=dtype)
+    if slots:
+        kw.update(groups=8, w_group_adapter=torch.tensor([0, 0, 1, 2, 0, 1, 2, 2], dtype=torch.int32, device=dev), n_per_adapter=N)
+    y16 = ops.gemm_mx8(ta, tw, **kw)
+    two = ops.quant_mx8(y16)
+    fused = ops.gemm_mx8(ta, tw, out_mx8=True, **kw)
+    assert fused.q.shape == (M, N // 2) and fused.shape == (M, N // 2)
+    assert torch.equal(fused.q, two.q), f"{(fused.q != two.q).sum().item()} bytes differ"
+    assert torch.equal(fused.scales[:, :M], two.scales[:, :M])
