@@ -32,7 +32,7 @@ with contextlib.redirect_stdout(io.StringIO()):
     revise_regionally_controlnet_forward(unet, ctl)
 masks = c2_masks(1024, 1024, device=dev)
 from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
-vae = AutoencoderKLDecoder(VaeConfig.sdxl(), dtype=torch.bfloat16, device=dev).init_synthetic_(seed=1)
+vae = AutoencoderKLDecoder(VaeConfig.sdxl(), dtype=torch.float16, device=dev, upcast=True).init_synthetic_(seed=1)      # the reference's upcast decode, as bench.py
 
 
 def reqs_for(n, seed0):
