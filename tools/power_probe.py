@@ -38,6 +38,14 @@ x0 = torch.zeros_like(x)
 burn("gemm_geglu_zero_A", lambda: ops.gemm(x0, w, act=L.ACT_GEGLU, out=out), 2 * M * N * K)
 xs = (torch.randn(M, K, device=dev) * 0.02).to(torch.float16)
 burn("gemm_geglu_small_A", lambda: ops.gemm(xs, w, act=L.ACT_GEGLU, out=out), 2 * M * N * K)
+xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+outb = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
+burn("gemm_geglu_bf16_random", lambda: ops.gemm(xb, wb, act=L.ACT_GEGLU, out=outb), 2 * M * N * K)
+outf = torch.empty(M, N, device=dev, dtype=torch.float16)
+burn("torch_matmul_bench_shape", lambda: torch.matmul(x, w.t(), out=outf), 2 * M * N * K)
+del outf
+xq, wq = ops.quant_mx8(x), ops.quant_mx8(w)
+burn("gemm_mx8_geglu_random", lambda: ops.gemm_mx8(xq, wq, act=L.ACT_GEGLU, out=out), 2 * M * N * K)
 a = torch.randn(8192, 8192, device=dev, dtype=torch.float16); b = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
 burn("torch_matmul_8192", lambda: torch.matmul(a, b), 2 * 8192 ** 3)
 q = torch.randn(64, 4096, 640, device=dev, dtype=torch.float16)
