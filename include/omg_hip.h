@@ -360,6 +360,20 @@ int omg_attn_probs(const omg_attn_args* a, void* P /*[B*heads, Nq, Nkv] dtype*/,
 int omg_attn_apply_probs(int dtype, const void* P, const void* V, int64_t ldv, int64_t v_bstride,
                          int B, int heads, int Nq, int Nkv, void* O, int64_t ldo, int64_t o_bstride, void* stream);
 
+/* ------------------------------------------------------------------------
+ * EfficientViT LiteMLA (the segmentation hand-off between the two stages: /root/reference
+ * src/efficientvit/models/nn/ops.py:335-455).  The qkv / grouped / proj 1x1 convolutions are omg_gemm launches; these are the rest.
+ * omg_dwconv2d: depthwise ksize x ksize convolution of the multi-scale aggregation (ops.py:372-380), NHWC rows of ldx / ldy
+ *   elements (so that it can read a column slice of the fused qkv buffer), weights [ksize*ksize][C] tap-major, stride 1, same padding.
+ * omg_relu_linear_att: relu_linear_att (ops.py:405-441) in fp32 as the reference computes it.  QKV [B*HW][ld]: group g holds its
+ *   q | k | v (dim each) at columns 3 dim g; OUT [B*HW][ldo]: group g at columns dim g.  dim in {8, 16, 32}.
+ * ---------------------------------------------------------------------- */
+int omg_dwconv2d(int dtype, const void* X, int64_t ldx, int B, int H, int W, int C, int ksize,
+                 const void* Wt, const void* bias, void* Y, int64_t ldy, void* stream);
+int64_t omg_relu_linear_att_ws_floats(int B, int groups, int dim, int HW);
+int omg_relu_linear_att(int dtype, const void* QKV, int64_t ld, int B, int HW, int groups, int dim, float eps,
+                        float* workspace, void* OUT, int64_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

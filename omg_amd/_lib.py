@@ -129,6 +129,9 @@ SYMBOLS = {
     "omg_gather_step": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "omg_attn_probs": (c_i32, [C.POINTER(AttnArgs), c_vp, c_vp]),
     "omg_attn_apply_probs": (c_i32, [c_i32, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_i64, c_vp]),
+    "omg_dwconv2d": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "omg_relu_linear_att_ws_floats": (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    "omg_relu_linear_att": (c_i32, [c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_i64, c_vp]),
     "omg_debug_set_glds": (None, [c_i32]),
     "omg_debug_set_gemm_variant": (None, [c_i32]),
     "omg_debug_choose_variant": (c_i32, [c_i32, c_i32, c_i32, c_i32]),

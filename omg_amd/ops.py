@@ -532,6 +532,31 @@ def layernorm_mx8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     return out
 
 
+def dwconv2d(x: torch.Tensor, taps: torch.Tensor, B: int, H: int, W: int, ksize: int, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Depthwise ``ksize x ksize`` convolution (stride 1, same padding) of NHWC rows ``x`` [B*H*W, C] (any row stride: a column slice
+    of a wider buffer is fine); ``taps`` [ksize*ksize, C] tap-major.  omg_dwconv2d — LiteMLA's multi-scale aggregation."""
+    _dev(x)
+    M, Cc = x.shape
+    assert M == B * H * W and x.stride(1) == 1 and taps.shape == (ksize * ksize, Cc) and taps.is_contiguous()
+    y = torch.empty((M, Cc), dtype=x.dtype, device=x.device)
+    L.check(L.lib().omg_dwconv2d(_dt(x), x.data_ptr(), x.stride(0), B, H, W, Cc, ksize, taps.data_ptr(), _p(bias), y.data_ptr(), y.stride(0), _stream()),
+            "omg_dwconv2d")
+    return y
+
+
+def relu_linear_att(qkv: torch.Tensor, B: int, HW: int, groups: int, dim: int, eps: float) -> torch.Tensor:
+    """EfficientViT's ReLU linear attention (fp32 inside) on NHWC rows ``qkv`` [B*HW, groups*3*dim] (group g: q | k | v at columns
+    3 dim g) -> [B*HW, groups*dim].  omg_relu_linear_att."""
+    _dev(qkv)
+    M, Cc = qkv.shape
+    assert M == B * HW and Cc == groups * 3 * dim and qkv.stride(1) == 1
+    out = torch.empty((M, groups * dim), dtype=qkv.dtype, device=qkv.device)
+    ws = torch.empty((int(L.lib().omg_relu_linear_att_ws_floats(B, groups, dim, HW)),), dtype=torch.float32, device=qkv.device)
+    L.check(L.lib().omg_relu_linear_att(_dt(qkv), qkv.data_ptr(), qkv.stride(0), B, HW, groups, dim, eps, ws.data_ptr(), out.data_ptr(), out.stride(0),
+                                        _stream()), "omg_relu_linear_att")
+    return out
+
+
 def conv_in(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
     """NCHW latents (fp32 or `dtype`) -> NHWC features in `dtype`; w: [Cout][64] from pack_conv_in_weight."""
     _dev(x_nchw)

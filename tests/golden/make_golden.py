@@ -3,7 +3,8 @@
     python tests/golden/make_golden.py        (needs /root/reference; writes *.npz next to itself)
 
 What can be imported from the reference: ``src/prompt_attention/*`` (with a stub
-``cv2`` module — p2p_utils.py:18 imports it and never uses it) and ``src/ip_adapter/*``.
+``cv2`` module — p2p_utils.py:18 imports it and never uses it), ``src/ip_adapter/*`` and — with bare package objects in place of
+the ``__init__`` files that import torchvision — ``src/efficientvit/models/nn/ops.py`` (LiteMLA).
 ``src/pipelines/*`` cannot (diffusers/peft are not installed), so no pipeline-level vectors exist.
 The fixtures pin: the oracle's controller restatement (facts T1-T6 + random tensors, including a
 non-identity mapper), and the IP-Adapter cross-attention processor arithmetic.
@@ -154,7 +155,39 @@ def resampler_vectors():
     print("resampler_golden.npz", {k: v.shape for k, v in out.items() if not k.startswith("sd.")})
 
 
+def litemla_vectors():
+    """EfficientViT LiteMLA (src/efficientvit/models/nn/ops.py:335-455), run by the reference's own class in eval mode.  The
+    package __init__ files of src/efficientvit import torchvision (not installed here); bare package objects are registered so
+    that only models/utils/*, models/nn/act.py, norm.py and ops.py are executed."""
+    import importlib
+    for name, sub in [("src.efficientvit", "src/efficientvit"), ("src.efficientvit.models", "src/efficientvit/models"),
+                      ("src.efficientvit.models.nn", "src/efficientvit/models/nn")]:
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(REF, sub)]
+            sys.modules[name] = m
+    ref_ops = importlib.import_module("src.efficientvit.models.nn.ops")
+    from oracle import litemla as ol
+    out = {}
+    cases = [("c64_d16", 64, 64, 16, (5,), 2, 8, 8, 11), ("c128_d32", 128, 96, 32, (5,), 1, 12, 10, 12), ("c64_d16_s35", 64, 64, 16, (3, 5), 2, 6, 6, 13)]
+    for tag, cin, cout, dim, scales, B, H, W, seed in cases:
+        m = ref_ops.LiteMLA(cin, cout, dim=dim, scales=scales).eval()
+        sd = ol.init_state_dict(cin, cout, dim, scales, seed=seed)
+        res = m.load_state_dict(sd, strict=False)
+        assert all(k.endswith("num_batches_tracked") for k in res.missing_keys) and not res.unexpected_keys, res
+        x = torch.randn(B, cin, H, W, generator=torch.Generator().manual_seed(5))
+        with torch.no_grad():
+            y = m(x)
+        out[f"{tag}_x"], out[f"{tag}_y"] = x.numpy(), y.numpy()
+        out[f"{tag}_cfg"] = np.array([cin, cout, dim, B, H, W] + list(scales))
+        for k, v in sd.items():
+            out[f"{tag}_sd_{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "litemla_golden.npz"), **out)
+    print("litemla_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    litemla_vectors()
     controller_vectors()
     ip_adapter_vectors()
     resampler_vectors()
