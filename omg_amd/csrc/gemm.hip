@@ -1475,6 +1475,7 @@ int launch(const GemmP& p, hipStream_t s) {
     if (v == 16) { if (v6ok) return launch_v8<T, CONV>(p, s, mrows); v = 11; }
     if (v == 15) { if (v6ok) return launch_v7<T, CONV>(p, s, mrows); v = 11; }
     if (v == 25) { if (v6ok) return launch_v7<T, CONV, 0, 4, 4, true>(p, s, mrows); v = 11; }
+#ifdef OMG_ABLATION_BUILDS   // make ABLATE=1: seven more instantiations of v7 for tools/gemm_ablate.py (3 minutes of compile time)
     if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
       if (v >= 17 && v <= 23 && v6ok) {
         switch (v - 16) {
@@ -1488,6 +1489,7 @@ int launch(const GemmP& p, hipStream_t s) {
         }
       }
     }
+#endif
     if (v == 13 || v == 14) { if (v6ok) return v == 13 ? launch_v6<T, CONV, 4>(p, s, mrows) : launch_v6<T, CONV, 2>(p, s, mrows); v = (v == 13) ? 11 : 12; }
     if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
     if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);

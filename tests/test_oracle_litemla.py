@@ -42,3 +42,24 @@ def test_linear_attention_identities():
     sd2["aggreg.0.0.weight"] = sd["aggreg.0.0.weight"].clone()
     y2 = ol.litemla_forward(sd2, x, dim=16)                # ... and the aggregated branch too: both convolutions are linear in k
     assert (y - y2).abs().max().item() < 1e-4
+
+
+def test_product_module_has_the_reference_state_dict_layout():
+    """omg_amd.litemla.LiteMLA must load a checkpoint of the reference's module key for key (shapes included); construction and
+    state-dict handling run on CPU, compute does not (no fallback)."""
+    import pytest
+    from omg_amd import _lib as L
+    from omg_amd.litemla import LiteMLA
+    for cin, cout, dim, scales in [(64, 64, 16, (5,)), (128, 96, 32, (5,)), (64, 64, 16, (3, 5))]:
+        sd = ol.init_state_dict(cin, cout, dim, scales, seed=1)
+        m = LiteMLA(cin, cout, dim=dim, scales=scales, dtype=torch.float16, device="cpu")
+        own = m.state_dict()
+        assert set(sd) <= set(own), set(sd) - set(own)
+        assert set(own) - set(sd) == {"proj.norm.num_batches_tracked"}
+        for k, v in sd.items():
+            assert tuple(own[k].shape) == tuple(v.shape), k
+        m.load_state_dict({k: v.half() if "running" not in k else v for k, v in sd.items()}, strict=False)
+        with pytest.raises(L.OmgHipError):
+            m(torch.zeros(1, cin, 4, 4, dtype=torch.float16))
+    with pytest.raises(L.OmgHipError):
+        LiteMLA(64, 64, dim=12)

@@ -1,6 +1,7 @@
 """Ablation of the v7 K loop (fp16 plain GEMM): which of LDS-DMA issue / fragment reads / the stage barrier costs what.
 Variants 17..23 = v7 with ablation bits (1 = no DMA in the loop, 2 = no fragment reads, 4 = no wait+barrier); results of the
-ablated kernels are wrong by construction, only their time is meaningful.  python tools/gemm_ablate.py [M N K]"""
+ablated kernels are wrong by construction, only their time is meaningful.  Needs the library built with `make -C omg_amd/csrc ABLATE=1`
+(the ablation instantiations are left out of the default build).  python tools/gemm_ablate.py [M N K]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
