@@ -3,9 +3,9 @@
 // fp32 statistics, deterministic reduction order (no float atomics), so the same
 // input gives bit-identical output on every run.
 //
-// GroupNorm is two launches: `gn_stats` writes per-(sample, pixel-chunk, group) partial
-// (sum, sumsq); `gn_apply` folds the partials in a fixed order (in fp64) into
-// mean/rstd, then streams y = silu?(x*scale + shift).  The second read of x is served
+// GroupNorm is three launches: `gn_stats` writes per-(sample, pixel-chunk, group) partial
+// (sum, sumsq); `gn_finalize` folds the partials in a fixed order (in fp64) into
+// mean/rstd; `gn_apply` streams y = silu?(x*scale + shift).  The second read of x is served
 // by L2 / Infinity Cache for every tensor on the SDXL path (<= 42 MB).
 #include "common.h"
 
@@ -91,6 +91,34 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnP p) {
   }
 }
 
+// One wave per (group, sample): folds the chunk partials in a FIXED order (lane l takes chunks l, l + 64, ...; then a butterfly
+// whose pairing does not depend on the data) in fp64 and leaves (mean, rstd) behind the partials in the workspace.  Until round 2
+// every block of gn_apply did this fold itself, 32 threads walking all the partials one dependent load after the other: with up to
+// 1024 chunks per sample that serial prologue was 80 % of the apply pass on the UNet's largest maps (4.6 ms for 4 GB of traffic).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(GnP p) {
+  const int g = blockIdx.x, b = p.b0 + blockIdx.y;
+  const int lane = threadIdx.x;
+  double ss = 0.0, qq = 0.0;
+  for (int ch = lane; ch < p.nchunk; ch += 64) {
+    const float* in = p.ws + (((long)b * GN_MAX_CHUNKS + ch) * p.G + g) * 2;
+    ss += (double)in[0]; qq += (double)in[1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    ss += __shfl_xor(ss, o);
+    qq += __shfl_xor(qq, o);
+  }
+  if (lane == 0) {
+    const double n = (double)p.HW * p.cpg;
+    const double mean = ss / n;
+    double var = qq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float* mr = p.ws + (long)p.B * GN_MAX_CHUNKS * p.G * 2 + ((long)b * p.G + g) * 2;
+    mr[0] = (float)mean;
+    mr[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+}
+
 // MX8 = true: the consumer is the MX-fp8 convolution (gemm_mx8.hip).  y is rounded to T exactly as the 16-bit kernel stores it,
 // then quantised per 32 consecutive channels (4 neighbouring lanes: two DPP exchanges for the amax) with the rule of
 // quant_mx8_kernel; the scale bytes go to S[c / 128][pixel][(c / 32) % 4] — the conv kernel fetches one dword per (output row,
@@ -101,18 +129,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = p.b0 + blockIdx.y;
   const int C = p.C1 + p.C2;
-  if (tid < p.G) {
-    double ss = 0.0, qq = 0.0;
-    for (int ch = 0; ch < p.nchunk; ++ch) {
-      const float* in = p.ws + (((long)b * GN_MAX_CHUNKS + ch) * p.G + tid) * 2;
-      ss += (double)in[0]; qq += (double)in[1];
-    }
-    const double n = (double)p.HW * p.cpg;
-    const double mean = ss / n;
-    double var = qq / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)mean;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+  if (tid < p.G) {      // mean / rstd of the sample's groups: folded once by gn_finalize_kernel
+    const float* mr = p.ws + (long)p.B * GN_MAX_CHUNKS * p.G * 2 + ((long)b * p.G + tid) * 2;
+    mean_s[tid] = mr[0];
+    rstd_s[tid] = mr[1];
   }
   __syncthreads();
   const int prow = tid / p.tpp, tv = tid - prow * p.tpp;
@@ -178,11 +198,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnP p) {
             amax = __builtin_fmaxf(amax, __shfl_xor(amax, 2));
             const unsigned be = mx8_scale_exp(amax);
             const float inv = mx8_inv_scale(be);
+            const int sc_mode = (C & 127) == 0 ? 2 : (C & 63) == 0 ? 1 : 0;
+            unsigned sc4 = be;                                   // every lane of the wave takes part in the exchanges
+            if (sc_mode >= 1) sc4 |= __shfl_down(be, 4) << 8;
+            if (sc_mode == 2) { sc4 |= __shfl_down(be, 8) << 16; sc4 |= __shfl_down(be, 12) << 24; }
             if (ok) {
               const long gp = (long)b * p.HW + px;
               u32x2 o = {mx8_pack4(r[0] * inv, r[1] * inv, r[2] * inv, r[3] * inv), mx8_pack4(r[4] * inv, r[5] * inv, r[6] * inv, r[7] * inv)};
               *(u32x2*)(p.Q + gp * p.Cq + vec * 8) = o;
-              if ((vec & 3) == 0) p.S[(((long)(vec >> 4) * p.P + gp) << 2) + ((vec >> 2) & 3)] = (unsigned char)be;
+              // scale bytes: one store per 128 channels (C % 128 == 0: the four block exponents sit in lanes vec, +4, +8, +12 of the
+              // same pixel and wave), per 64 channels (C % 64 == 0), else per block — single-byte stores cost a transaction each
+              if (sc_mode == 2) { if ((vec & 15) == 0) *(unsigned*)(p.S + (((long)(vec >> 4) * p.P + gp) << 2)) = sc4; }
+              else if (sc_mode == 1) { if ((vec & 7) == 0) *(unsigned short*)(p.S + (((long)(vec >> 4) * p.P + gp) << 2) + ((vec >> 2) & 3)) = (unsigned short)sc4; }
+              else if ((vec & 3) == 0) p.S[(((long)(vec >> 4) * p.P + gp) << 2) + ((vec >> 2) & 3)] = (unsigned char)be;
               const int cpad = C + vec * 8;      // the first (Cq - C) / 8 lanes of the pixel also clear its pad channels
               if (cpad < p.Cq) {
                 *(u32x2*)(p.Q + gp * p.Cq + cpad) = u32x2{0u, 0u};
@@ -344,7 +372,7 @@ extern "C" int omg_layernorm_mx8(int dtype, const void* X, int64_t ldx, int M, i
 
 extern "C" int64_t omg_groupnorm_ws_floats(int B, int groups, int HW) {
   (void)HW;
-  return (int64_t)B * GN_MAX_CHUNKS * groups * 2;
+  return (int64_t)B * GN_MAX_CHUNKS * groups * 2 + (int64_t)B * groups * 2;      // chunk partials + (mean, rstd) per (sample, group)
 }
 
 namespace {
@@ -387,14 +415,17 @@ int gn_run(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int
     dim3 grid(nchunk, nb);
     if (dtype == OMG_F16) {
       OMG_LAUNCH(gn_stats_kernel<f16>, grid, dim3(256), lds, s, p);
+      OMG_LAUNCH(gn_finalize_kernel, dim3(p.G, nb), dim3(64), 0, s, p);
       if (mx8) OMG_LAUNCH((gn_apply_kernel<f16, true>), grid, dim3(256), 0, s, p);
       else OMG_LAUNCH((gn_apply_kernel<f16, false>), grid, dim3(256), 0, s, p);
     } else if (dtype == OMG_BF16) {
       OMG_LAUNCH(gn_stats_kernel<bf16>, grid, dim3(256), lds, s, p);
+      OMG_LAUNCH(gn_finalize_kernel, dim3(p.G, nb), dim3(64), 0, s, p);
       if (mx8) OMG_LAUNCH((gn_apply_kernel<bf16, true>), grid, dim3(256), 0, s, p);
       else OMG_LAUNCH((gn_apply_kernel<bf16, false>), grid, dim3(256), 0, s, p);
     } else {          // fp32 storage: the up-blocks of the upcast VAE decode (lora_pipeline.py:639-652)
       OMG_LAUNCH(gn_stats_kernel<float>, grid, dim3(256), lds, s, p);
+      OMG_LAUNCH(gn_finalize_kernel, dim3(p.G, nb), dim3(64), 0, s, p);
       OMG_LAUNCH((gn_apply_kernel<float, false>), grid, dim3(256), 0, s, p);
     }
   }
