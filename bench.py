@@ -77,24 +77,31 @@ class PowerSampler:
         self.dev, self.period, self.rows, self._stop = device_index, period, [], False
         self._th = threading.Thread(target=self._run, daemon=True)
 
+    @staticmethod
+    def parse(text):
+        """One `rocm-smi -d N -c -P --showmaxpower --json` answer -> {"sclk": MHz, "w": W, "cap": W} (keys present when found)."""
+        import re
+        card = next(iter(json.loads(text).values()))
+        row = {}
+        for k, v in card.items():
+            kl = k.lower()
+            m = re.search(r"[-+]?\d+(\.\d+)?", str(v))
+            if m is None:
+                continue
+            if "sclk clock speed" in kl:
+                row["sclk"] = float(m.group())
+            elif "max graphics package power" in kl:
+                row["cap"] = float(m.group())
+            elif "power (w)" in kl and "max" not in kl:
+                row["w"] = float(m.group())
+        return row
+
     def _run(self):
-        import re, subprocess
+        import subprocess
         while not self._stop:
             try:
                 o = subprocess.run(["rocm-smi", "-d", str(self.dev), "-c", "-P", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10).stdout
-                card = next(iter(json.loads(o).values()))
-                row = {}
-                for k, v in card.items():
-                    kl = k.lower()
-                    m = re.search(r"[-+]?\d+(\.\d+)?", str(v))
-                    if m is None:
-                        continue
-                    if "sclk clock speed" in kl:
-                        row["sclk"] = float(m.group())
-                    elif "max graphics package power" in kl:
-                        row["cap"] = float(m.group())
-                    elif "power (w)" in kl and "max" not in kl:
-                        row["w"] = float(m.group())
+                row = self.parse(o)
                 if row:
                     self.rows.append(row)
             except Exception:      # noqa: BLE001 - no rocm-smi, odd output: the line is simply reported without power

@@ -83,3 +83,25 @@ def test_reference_is_not_needed_at_runtime():
         src = open(os.path.join(ROOT, path)).read()
         code = "\n".join(l for l in src.splitlines() if "sys.path" in l or "open(" in l or "import " in l)
         assert "/root/reference" not in code, path
+
+
+def test_bench_power_sampler_parses_rocm_smi_json():
+    """bench.py's `power` object: the rocm-smi JSON of one poll -> clock / power / cap (no GPU needed for the parser)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("omg_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    txt = ('{"card0": {"Temperature (Sensor junction) (C)": "45.0", "sclk clock speed:": "(1857Mhz)", "sclk clock level:": "1", '
+           '"mclk clock speed:": "(2000Mhz)", "Current Socket Graphics Package Power (W)": "1102.0", "Max Graphics Package Power (W)": "1400.0"}}')
+    assert bench.PowerSampler.parse(txt) == {"sclk": 1857.0, "w": 1102.0, "cap": 1400.0}
+    s = bench.PowerSampler(0)
+    s.rows = [{"sclk": 1600.0, "w": 1400.0, "cap": 1400.0}, {"sclk": 1700.0, "w": 1390.0}]
+    out = s.summary()
+    assert out["avg_sclk_mhz"] == 1650.0 and out["avg_w"] == 1395.0 and out["cap_w"] == 1400.0 and out["samples"] == 2
+
+
+def test_groupnorm_workspace_holds_partials_and_folded_statistics():
+    from omg_amd import _lib
+    lib = _lib.lib()
+    B, G = 64, 32
+    assert lib.omg_groupnorm_ws_floats(B, G, 16384) == B * 1024 * G * 2 + B * G * 2
