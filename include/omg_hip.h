@@ -48,7 +48,7 @@ enum {
 };
 
 int omg_abi_version(void);
-/* last launch error string (thread-unsafe, debugging aid) */
+/* message of the last failed call made by the CALLING thread (thread-local storage; valid until that thread's next failing call) */
 const char* omg_last_error(void);
 
 /* ------------------------------------------------------------------------

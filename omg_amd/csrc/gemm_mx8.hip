@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
   // (CONV: wave 1 stages the W scales this way; the A scales are fetched per row by every wave, below.)
   const bool sA = !CONV && w == 0;
   const bool sc_wave = CONV ? w == 1 : w < 2;
+  // with weight slots the W-scale base is shifted by the slot's columns: the descriptor ends where the tensor ends, and a
+  // lane's rows are bounded by the slot's N rows (not by the row count of all slots)
+  const long s_shift = (!sA && p.w_adapter_stride != 0) ? (long)adapter * p.sw_adapter_stride * 4 : 0;
   const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(sA ? p.SA : SWp), 0,
-      (int)((long)nk * (sA ? p.sa_ld : p.sw_ld) * 4), 0x00020000);
+      (int)((long)nk * (sA ? p.sa_ld : p.sw_ld) * 4 - s_shift), 0x00020000);
   const int s_step = (sA ? p.sa_ld : p.sw_ld) * 4;                     // bytes between stages
-  const int s_rows = (sA ? p.sa_ld : p.sw_ld);
+  const int s_rows = sA ? p.sa_ld : (p.w_adapter_stride != 0 ? (p.N + 3) & ~3 : p.sw_ld);
   // a lane carries 4 consecutive rows' dwords; rows past the array's row count must not wrap into the next stage's rows
   const int s_row0 = (sA ? m0 : n0) + lane * 4;
   const int voffS = s_row0 + 3 < s_rows ? s_row0 * 4 : 0x7ffffff0;

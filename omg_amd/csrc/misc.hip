@@ -3,7 +3,8 @@
 #include "common.h"
 #include <string.h>
 
-static char g_err[256] = "";
+// per calling thread: entry points are re-entrant across host threads / streams (B5), so is their diagnostic
+static thread_local char g_err[256] = "";
 void omg_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); g_err[sizeof(g_err) - 1] = 0; }
 extern "C" const char* omg_last_error(void) { return g_err; }
 extern "C" int omg_abi_version(void) { return OMG_ABI_VERSION; }

@@ -393,6 +393,11 @@ int gn_run(int dtype, const void* X1, int C1, const void* X2, int C2, int B, int
   p.vpt = p.nvec <= 256 ? 1 : 2;
   p.tpp = p.vpt == 1 ? p.nvec : (p.nvec + 1) / 2;
   p.pr = 256 / p.tpp;
+  if (mx8) {   // the 32-channel amax and the scale-byte gathers exchange between NEIGHBOURING lanes of one pixel: a pixel's lanes must
+               // start on a multiple of the exchange width (always true for one vector per lane; C > 2048 needs C % 256 / 128 / 64 == 0)
+    const int need = (C & 127) == 0 ? 16 : (C & 63) == 0 ? 8 : 4;
+    OMG_REQUIRE(p.tpp % need == 0, "omg_groupnorm_mx8: C > 2048 needs C/16 to be a multiple of the scale-exchange width");
+  }
   long elems = (long)HW * C;
   int nchunk = (int)((elems + 32767) / 32768);
   if (nchunk > GN_MAX_CHUNKS) nchunk = GN_MAX_CHUNKS;

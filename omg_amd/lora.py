@@ -81,7 +81,7 @@ class LoraBank:
 
     def build(self, slots: Sequence[Sequence[Tuple[str, float]]], scale: float = 1.0, mode: str = "merged") -> None:
         """Materialise the slot stacks on every target Linear.  ``slots[s]`` = [(adapter name, weight), ...];
-        ``scale`` is ``cross_attention_kwargs['scale']`` (0.8 in OMG, lora_pipeline.py:596).
+        ``scale`` is ``cross_attention_kwargs['scale']`` (0.8 in OMG, lora_pipeline.py:596) — a float, or one value per slot.
 
         mode="segment": keep A/B un-merged (PEFT's arithmetic: base(x) + s*B(A(x)), second K-segment of omg_gemm).
         mode="merged" : additionally build ``w_slots[1+S, out, in] = [W, W + s*B_1 A_1, ...]`` (fp32 merge, one
@@ -91,7 +91,12 @@ class LoraBank:
             raise ValueError(mode)
         self.mode = mode
         self.slots = [tuple((n, float(w)) for n, w in s) for s in slots]
-        self.scale = scale
+        # one scale for every slot, or one per slot (the reference's concept passes hard-code 0.8, lora_pipeline.py:596, while
+        # the main pass's style adapter takes the caller's cross_attention_kwargs["scale"], :546-566)
+        per_slot = [float(x) for x in scale] if isinstance(scale, (list, tuple)) else [float(scale)] * len(self.slots)
+        if len(per_slot) != len(self.slots):
+            raise ValueError("one LoRA scale per slot")
+        self.scale = tuple(per_slot) if isinstance(scale, (list, tuple)) else scale
         dev, dt = self.unet.device, self.unet.dtype
         keys = set()
         for a in self.adapters.values():
@@ -115,7 +120,7 @@ class LoraBank:
                     a, b = ad.weights[key]
                     r = a.shape[0]                                   # <= ad.rank; the rest of the adapter's band stays zero
                     down[s, r0:r0 + r] = a.to(dev).float()
-                    up[s, :, r0:r0 + r] = b.to(dev).float() * (scale * w * ad.scaling(key))
+                    up[s, :, r0:r0 + r] = b.to(dev).float() * (per_slot[s] * w * ad.scaling(key))
                     r0 += ad.rank
             lin.lora_down = down.to(dt).contiguous()
             lin.lora_up = up.to(dt).contiguous()

@@ -35,6 +35,7 @@ from .modules import LoraState, pointer_epoch
 from .schedulers import DDIMScheduler
 
 FUSION_START = 15   # `if i > 15 and stage == 2` (lora_pipeline.py:568) — absolute, not relative
+CONCEPT_LORA_SCALE = 0.8   # `cross_attention_kwargs={'scale': 0.8}` of every concept UNet call (lora_pipeline.py:596), whatever the caller passes
 
 
 def revise_regionally_controlnet_forward(unet, controller) -> None:
@@ -325,20 +326,24 @@ class LoraMultiConceptPipeline:
         # MAIN pass: inference_lora.py:162-164 loads the style LoRA into the main pipe as well, and the main UNet is called with
         # cross_attention_kwargs={"scale": 0.8} (:546-566), so with styleL every main sample runs with adapter "style" at PEFT
         # weight 1.0 x scale — one more slot of the same bank, selected for the main rows in plain AND fused steps.
-        scale = (cross_attention_kwargs or {}).get("scale", 1.0)
+        # LoRA scale: the concept UNet is always called with cross_attention_kwargs={'scale': 0.8} (hard-coded, :592-598); the main UNet
+        # (style slot) with the caller's cross_attention_kwargs (:546-566; PEFT's default scale is 1.0)
+        main_scale = float((cross_attention_kwargs or {}).get("scale", 1.0))
         bank = concept_models.bank if concept_models is not None else None
         combos = []
         if fuse_possible:
             combos = [((lora_list[c], 0.7), ("style", 0.5)) if styleL else ((lora_list[c], 1.0),) for c in active]
+        scales = [CONCEPT_LORA_SCALE] * len(combos)
         main_slot = -1
         if styleL:
             if bank is None or "style" not in bank.adapters:
                 raise ValueError("styleL=True needs concept_models with a LoraBank holding the adapter named 'style'")
             main_slot = len(combos)
             combos = combos + [(("style", 1.0),)]
+            scales.append(main_scale)
         if bank is not None and combos:
-            if [tuple(c) for c in combos] != list(bank.slots) or bank.scale != scale or bank.mode != lora_mode:
-                bank.build(combos, scale=scale, mode=lora_mode)
+            if [tuple(c) for c in combos] != list(bank.slots) or bank.scale != tuple(scales) or bank.mode != lora_mode:
+                bank.build(combos, scale=scales, mode=lora_mode)
         if fuse_possible:
             slots = [s for _ in range(n) for s in range(Ka) for _ in range(2)] if bank is not None else [-1] * ncn
             c_ehs = torch.cat(cehs_l, dim=0).contiguous()                                           # (2Ka*n, 77, Cx)

@@ -219,8 +219,10 @@ def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_
     [(name, weight), ...] (the reference calls ``concept_models.set_adapters(lora)`` / ``set_adapters([lora, "style"], [0.7, 0.5])``
     right before ``concept_models.encode_prompt(..., lora_scale=0.8)``, lora_pipeline.py:336-347).  ``adapters`` maps names to
     :class:`omg_amd.lora.LoraAdapter` objects whose ``text_encoder[1]`` / ``[2]`` hold the CLIP-L / OpenCLIP-bigG halves of the LoRA
-    file (omg_amd/loaders.py); an adapter without text-encoder entries changes nothing."""
+    file (omg_amd/loaders.py); an adapter without text-encoder entries changes nothing.  When ``adapters`` is given, a name missing from
+    it is an error; when it is omitted (``make_encode_prompt(enc_l, enc_g, tok_l, tok_g)``), every adapter is taken to be UNet-only."""
     tokenize_g = tokenize_g or tokenize_l
+    strict = adapters is not None      # an explicit table must know every name; without one, adapters have no text-encoder half
     adapters = adapters if adapters is not None else {}
 
     def _list(p, n):
@@ -234,7 +236,9 @@ def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_
             act = []
             for name, w in combo:
                 if name not in adapters:
-                    raise KeyError(f"text-encoder LoRA: adapter {name!r} was not given to make_encode_prompt(adapters=...)")
+                    if strict:
+                        raise KeyError(f"text-encoder LoRA: adapter {name!r} was not given to make_encode_prompt(adapters=...)")
+                    continue       # a UNet-only adapter changes nothing in the text encoders (PEFT: no lora layers there)
                 act.append((adapters[name].text_encoder.get(n_te), ls * float(w)))
             enc.set_lora(act)
         try:

@@ -32,7 +32,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from .attention import Attention, FusedAttnProcessor
-from .modules import Conv2d, GEGLU, GroupNorm, LayerNorm, Linear, LoraState
+from .modules import Conv2d, GEGLU, GroupNorm, LayerNorm, Linear, LoraState, bump_pointer_epoch
 
 
 @dataclass
@@ -371,12 +371,17 @@ class UNet2DConditionModel(nn.Module):
         if mode not in ("fp16", "mx8"):
             raise ValueError(mode)
         on = mode == "mx8"
+        changed = False
         for name, m in self.named_modules():
             if isinstance(m, Linear):
                 in_block = ".attentions." in name and not (name.endswith(".to_k") or name.endswith(".to_v")) or \
                            (".attentions." in name and ".attn1." in name)
-                m.mx8 = on and in_block and m.in_features % 128 == 0
+                new = on and in_block and m.in_features % 128 == 0
+                changed |= bool(getattr(m, "mx8", False)) != new
+                m.mx8 = new
         self.linear_precision = mode
+        if changed:      # step graphs captured under the other precision launch the other kernels: drop them (pipeline.run_step)
+            bump_pointer_epoch()
 
     def set_conv_precision(self, mode: str = "fp16") -> None:
         """``"mx8"``: conv1 / conv2 of every ResnetBlock2D run as MX-fp8 implicit GEMMs (omg_conv2d_mx8) on the feature map their
@@ -385,10 +390,14 @@ class UNet2DConditionModel(nn.Module):
         the time-embedding projection added as per-sample bias, the skip connection added in the epilogue."""
         if mode not in ("fp16", "mx8"):
             raise ValueError(mode)
+        changed = False
         for m in self.modules():
             if isinstance(m, ResnetBlock2D):
+                changed |= bool(getattr(m.conv1, "mx8", False)) != (mode == "mx8")
                 m.conv1.mx8 = m.conv2.mx8 = mode == "mx8"
         self.conv_precision = mode
+        if changed:
+            bump_pointer_epoch()
 
     # ------------------------------------------------------------------ LoRA selection
     def set_lora_state(self, state: Optional[LoraState]) -> None:

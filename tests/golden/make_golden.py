@@ -89,6 +89,29 @@ def controller_vectors():
     print("controller_golden.npz:", len(out), "arrays")
 
 
+def controller_alignment_vectors():
+    """Round 3: harder alignment cases for the product's own (run-offset) construction of the mapper / alpha tables — several edited
+    prompts, several replaced words per prompt, replaced words with different piece counts on either side, word-specific
+    windows that hit more than one token — all produced by the reference's seq_aligner / p2p_utils."""
+    from src.prompt_attention import p2p_utils
+    out = {}
+    cases = [
+        (["a man on the road", "a woman on the road", "a superman on the road"], "piece"),
+        (["photograph of a man walking the dog", "photograph of a woman walking the cat"], "piece"),
+        (["extraordinarily dog in the garden", "x superman in the street"], "piece"),
+        (["a man and a woman walking on the street", "a dog and a cat walking on the street"], "white"),
+        (["woman woman woman", "man x woman"], "piece"),
+    ]
+    for n, (prompts, tk) in enumerate(cases):
+        tok = PieceTokenizer() if tk == "piece" else WhitespaceTokenizer()
+        out[f"c{n}_mapper"] = seq_aligner.get_replacement_mapper(prompts, tok).numpy()
+        for m, (S, spec) in enumerate([(50, {"default_": 1.0}), (10, {"default_": 0.6, prompts[1].split(" ")[-1]: (0.2, 0.9)}),
+                                       (7, {"default_": (0.1, 0.8), prompts[1].split(" ")[0]: 0.3})]):
+            out[f"c{n}_alpha{m}"] = p2p_utils.get_time_words_attention_alpha(prompts, S, dict(spec), tok).numpy()
+    np.savez_compressed(os.path.join(HERE, "controller_alignment_golden.npz"), **out)
+    print("controller_alignment_golden.npz:", len(out), "arrays")
+
+
 class _FakeAttn(torch.nn.Module):
     """The slice of diffusers' Attention interface the IP-Adapter processors touch."""
 
@@ -189,5 +212,6 @@ def litemla_vectors():
 if __name__ == "__main__":
     litemla_vectors()
     controller_vectors()
+    controller_alignment_vectors()
     ip_adapter_vectors()
     resampler_vectors()

@@ -86,6 +86,29 @@ def test_controller_general_mapper_matches_reference(gold):
         pc.get_replacement_mapper(["a man", "a man walking"], oc.WhitespaceTokenizer())
 
 
+ALIGN_CASES = [
+    (["a man on the road", "a woman on the road", "a superman on the road"], "piece"),
+    (["photograph of a man walking the dog", "photograph of a woman walking the cat"], "piece"),
+    (["extraordinarily dog in the garden", "x superman in the street"], "piece"),
+    (["a man and a woman walking on the street", "a dog and a cat walking on the street"], "white"),
+    (["woman woman woman", "man x woman"], "piece"),
+]
+
+
+@pytest.mark.parametrize("n", range(len(ALIGN_CASES)))
+def test_alignment_tables_match_reference_generated_vectors(n):
+    """The package builds the mapper from run offsets and the alpha table from broadcast windows (omg_amd/controller.py); the vectors
+    are the reference's own seq_aligner / p2p_utils outputs (tests/golden/make_golden.py: controller_alignment_vectors): several
+    edited prompts, several replaced words, unequal piece counts, word windows that hit several tokens.  Bit-exact."""
+    gold = np.load(os.path.join(GOLD, "controller_alignment_golden.npz"))
+    prompts, tk = ALIGN_CASES[n]
+    tok = oc.PieceTokenizer() if tk == "piece" else oc.WhitespaceTokenizer()
+    assert np.array_equal(pc.get_replacement_mapper(prompts, tok).numpy(), gold[f"c{n}_mapper"])
+    specs = [(50, {"default_": 1.0}), (10, {"default_": 0.6, prompts[1].split(" ")[-1]: (0.2, 0.9)}), (7, {"default_": (0.1, 0.8), prompts[1].split(" ")[0]: 0.3})]
+    for m, (S, spec) in enumerate(specs):
+        assert np.array_equal(pc.get_time_words_attention_alpha(prompts, S, dict(spec), tok).numpy(), gold[f"c{n}_alpha{m}"]), (n, m)
+
+
 @pytest.mark.parametrize("n", [50, 30, 10])
 def test_scheduler_tables_reproduce_the_oracle_schedulers(n):
     rng = np.random.default_rng(0)
