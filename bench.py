@@ -18,7 +18,12 @@ Inputs are resident in HBM before the timed region.  N > 1: one process per GPU,
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (GEMM/conv kernel family, MFMA-bound, HIP-event
 timed in an instrumented pass of one plain + one fused denoising step) and "cpu_baseline" (the fp32 oracle on
-the host cores, bounded sample, extrapolated).
+the host cores, bounded sample, extrapolated).  "value" is the reference's as-executed work (336 sample-forwards per
+image); "value_dedup" is the same images with the exactly redundant sample-forwards of steps 0..15 executed once
+(bitwise the same latents, tests/test_pipeline_gpu.py), timed in a second, shorter region.
+
+`python bench.py --gpus N` without a torch.distributed environment re-launches itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU).
 """
 import argparse
 import json
@@ -39,8 +44,10 @@ PEAK_TFLOPS = 2500.0              # dense bf16/fp16 MFMA peak, MI355X (MI355X_MI
 
 
 def cpu_baseline(args):
-    """Oracle (CPU restatement of the reference path) timed on the host cores: ONE fp32 UNet sample-forward at
-    full SDXL width; latent side 64 (512^2 image) by default to stay within ~30 s, scaled by the analytic FLOP ratio."""
+    """Oracle (CPU restatement of the reference path) timed on the host cores: ONE fp32 UNet sample-forward at full SDXL width and
+    at the workload's own shape (latent 128 = the 1024^2 image; ~45 s on the GPU box's 128 threads), extrapolated by the forward
+    count to one image.  SURVEY §8d's sample (a plain + a fused full-shape step = 12 such forwards, ~9 min) does not fit a
+    default run; --cpu-latent 64 times the 512^2 forward instead (~10 s, scaled by the analytic FLOP ratio)."""
     from oracle import unet as ou
     torch.manual_seed(0)
     ocfg = ou.UNetConfig.sdxl()
@@ -136,7 +143,8 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-latent", type=int, default=64, choices=[64, 128])
+    ap.add_argument("--cpu-latent", type=int, default=128, choices=[64, 128])
+    ap.add_argument("--dedup-steps", type=int, default=-1, help="steps of the second timed region (value_dedup); -1 = min(--steps, 2), 0 = skip")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet (NOT a valid benchmark)")
     ap.add_argument("--images-per-step", type=int, default=8, help="independent requests run in lock-step per step (one batched UNet forward)")
     ap.add_argument("--by-shape", default="", help="also write the roofline leg's per-shape table (ms per bench step, TF/s) to this file")
@@ -146,6 +154,15 @@ def main():
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for power / clock during the timed region")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU over RCCL), as the N > 1 contract describes
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     from omg_amd import controller as pc, ops, parallel
     from omg_amd.pipeline import LoraMultiConceptPipeline, revise_regionally_controlnet_forward
@@ -192,12 +209,12 @@ def main():
             reqs.append(r)
         inputs.append(reqs)
 
-    def run_step(reqs):
+    def run_step(reqs, dedup=False):
         """One bench step = `ips` complete stage-2 calls (independent requests batched through the UNet in lock-step)."""
         ctl.reset()                                                                   # inference_lora.py:274
         lat = pipe.generate_many(reqs, height=HW, width=HW, num_inference_steps=args.denoise_steps, guidance_scale=7.5,
                                  cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
-                                 lora_list=["concept0", "concept1"], styleL=False, use_graph=not args.no_graph)
+                                 lora_list=["concept0", "concept1"], styleL=False, use_graph=not args.no_graph, dedup=dedup)
         if vae is not None:                                                           # both images of every request, two at a time
             for j in range(lat.shape[0]):
                 img = vae.decode_latents(lat[j])
@@ -225,8 +242,33 @@ def main():
     assert torch.isfinite(allimg).all()
     value = world * ips * args.steps / el
 
+    # second timed region: the same requests with the exactly redundant forwards executed once (same barrier / sync bracket)
+    n_dd = min(args.steps, 2) if args.dedup_steps < 0 else min(args.dedup_steps, n_steps)
+    dedup = None
+    if n_dd > 0:
+        lat_full = lat
+        lat_dd = run_step(inputs[n_steps - 1], dedup=True)          # warm-up of the dedup engine (captures its step graphs)
+        same = bool(torch.equal(lat_dd, lat_full))                    # same inputs as the last timed step: must be the same bits
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps - n_dd, n_steps):
+            lat = run_step(inputs[i], dedup=True)
+            parallel.gather_latents(lat[:, 1].contiguous(), world * ips, rank, world)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        el_dd = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        n_twin = min(16, args.denoise_steps)                          # steps 0..15 precede the first fused step (i > 15)
+        dedup = {"value": world * ips * n_dd / el_dd, "steps": n_dd, "ms_per_step": 1000.0 * el_dd / n_dd,
+                 "sample_forwards_executed": N_MAIN + N_CONCEPT - 2 * n_twin, "sample_forwards_reference": N_MAIN + N_CONCEPT,
+                 "latents_bitwise_equal_to_full_run": same,
+                 "what": "steps 0..15 of a stage-2 call: samples 0 and 1 share latents and prompts (lora_pipeline.py:397-409, :568), so "
+                         "[unc, cond] runs once per request and is written to both samples"}
+
     out = {"metric": "images/sec @ SDXL 1024^2 50-step, 2-concept mask fusion", "value": value, "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * el / args.steps,
+           "value_dedup": dedup["value"] if dedup else None, "dedup": dedup,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": ("fp8 (OCP MX e4m3 operands, fp32 accumulate) on the transformer Linear layers" + ("" if args.fp8_linear_only else " and the resnet 3x3 convolutions with Cin % 128 == 0")
                      + "; fp16 elsewhere") if args.dtype == "fp8" else args.dtype,
@@ -273,19 +315,17 @@ def main():
         # HBM-side bytes cannot be counted from inside this process: the committed rocprofv3 --pmc measurement of the
         # dominant GEMM shape (profiles/r01_pmc_traffic.json, method and gfx950 correction recorded there) is reported
         traffic, traffic_note = None, "no PMC measurement committed"
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        tfile = "r03_pmc_traffic_fp8.json" if args.dtype == "fp8" else "r03_pmc_traffic_fp16.json"
+        try:      # tools/pmc_traffic.py wrote it from rocprofv3 --pmc passes of the kernel this line's roofline names
+            with open(os.path.join(ROOT, "profiles", tfile)) as f:
                 pm = json.load(f)
             traffic = pm["traffic_bytes_per_launch"]
-            traffic_note = ("bytes per launch of the largest GEMM (M 65536, N 10240, K 1280; %.2f GB algorithmic) from rocprofv3 --pmc "
-                            "FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes: profiles/r01_pmc_traffic.json"
-                            % ((pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"]) / 1e9))
+            traffic_note = ("bytes per launch of the largest GEMM (%s; %.2f GB algorithmic) from rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) "
+                            "+ WRITE_SIZE, separate passes: profiles/%s" % (pm["shape"], (pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"]) / 1e9, tfile))
         except (OSError, KeyError, ValueError):
             pass
         kname = ("gemm_mx8_kernel (transformer Linear layers + resnet convolutions, MX-fp8 operands on v_mfma_scale_f32_32x32x64_f8f6f4, per-sample weight slots)"
                  if args.dtype == "fp8" else "gemm_kernel_v7 / gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)")
-        if args.dtype == "fp8":
-            traffic, traffic_note = None, "not measured for the MX-fp8 kernel"
         out["roofline"] = {"bound": "mfma", "kernel": kname,
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                            "traffic_note": traffic_note,

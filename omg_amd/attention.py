@@ -245,6 +245,9 @@ class FusedAttnProcessor:
     def _qk_src(self, attn, is_cross: bool, n_tokens: int, batch: int, device, main_batch=None, images=1):
         return None
 
+    def _skip_layer(self) -> None:
+        return None
+
     def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  scale: float = 1.0, residual: Optional[torch.Tensor] = None, **cross_attention_kwargs):
         if attention_mask is not None:
@@ -260,7 +263,10 @@ class FusedAttnProcessor:
         bypass = cross_attention_kwargs.pop("omg_bypass_controller", False)
         main_b = cross_attention_kwargs.pop("omg_main_batch", None)       # p2p batch per request [unc0,unc1,cond0,cond1]
         n_img = cross_attention_kwargs.pop("omg_images", 1)               # requests batched in lock-step
-        src = None if bypass else self._qk_src(attn, is_cross, N, B, x.device, main_b, n_img)
+        twin = cross_attention_kwargs.pop("omg_twin", False)               # rows are [unc, cond] of requests whose two samples coincide
+        if twin and not bypass:
+            self._skip_layer()
+        src = None if (bypass or twin) else self._qk_src(attn, is_cross, N, B, x.device, main_b, n_img)
         ip_ctx = cross_attention_kwargs.pop("omg_ip_tokens", None)         # (rows, 16, Cx) image-prompt tokens of the rows
         ip_row0 = cross_attention_kwargs.pop("omg_ip_rows", 0)             #   [ip_row0:] of the batch (InstantID concept samples)
         o = ops.attention(q, k, vt, attn.heads, attn.scale, qk_src=src)
@@ -286,6 +292,11 @@ class RegionControlNet_AttnProcessor(FusedAttnProcessor):
             return None
         return self.controller.fused_qk_src(is_cross, n_tokens, main_batch or batch, self.place_in_unet, device=device,
                                             total_batch=batch, images=images)
+
+    def _skip_layer(self) -> None:
+        """The edited sample IS the base sample (pipeline ``dedup``): the replacement is the identity, only the counters move."""
+        if self.controller is not None:
+            self.controller.skip_layer()
 
     def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  scale: float = 1.0, residual: Optional[torch.Tensor] = None, **cross_attention_kwargs):

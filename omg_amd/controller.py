@@ -249,6 +249,13 @@ class AttentionReplace:
             self._src_cache[key] = t
         return t
 
+    def skip_layer(self) -> None:
+        """One attention call whose conditional samples are all identical to the base sample (the caller has proven it): a pure
+        replacement leaves them unchanged, so only the layer / step counters advance — exactly as ``__call__`` would."""
+        if not self.is_pure_replacement:
+            raise RuntimeError("skip_layer needs a pure-replacement controller")
+        self._tick()
+
     def fused_qk_src(self, is_cross: bool, n_tokens: int, batch: int, place_in_unet: str = "",
                      device=None, total_batch: Optional[int] = None, images: int = 1) -> Optional[torch.Tensor]:
         if not self.is_pure_replacement:

@@ -131,7 +131,9 @@ class LoraMultiConceptPipeline:
         self.encode_prompt = encode_prompt
         self.vae_decode = vae_decode
         self.vae_scale_factor = 8
-        self._engines: Dict[Tuple, SimpleNamespace] = {}
+        self._engines: Dict[Tuple, SimpleNamespace] = {}      # call shape -> static buffers + captured step graphs, LRU
+        self.max_engines = 8                                   # a few hundred MB of buffers each (+ graph pools): raise for servers with many shapes
+        self.engine_evictions = 0
 
     @property
     def _execution_device(self):
@@ -175,7 +177,7 @@ class LoraMultiConceptPipeline:
                  region_masks: Optional[Sequence[Optional[torch.Tensor]]] = None, lora_list: Optional[Sequence[str]] = None,
                  styleL: Optional[bool] = None, region_prompt_embeds: Optional[Sequence[Tuple[torch.Tensor, ...]]] = None,
                  use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START,
-                 lora_mode: str = "merged", **kwargs):
+                 lora_mode: str = "merged", dedup: bool = False, **kwargs):
         controlnet = kwargs.pop("controlnet", getattr(self, "controlnet", None))
         if image is not None and controlnet is None:
             raise L.OmgHipError("image= needs a ControlNet: pass controlnet=omg_amd.controlnet.ControlNetModel(...)")
@@ -217,7 +219,7 @@ class LoraMultiConceptPipeline:
                                  controller=controller, concept_models=concept_models, stage=stage, lora_list=lora_list,
                                  styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
                                  lora_mode=lora_mode, controlnet=controlnet if image is not None else None, controlnet_image=image,
-                                 controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0))[0]
+                                 controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0), dedup=dedup)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         images = self._postprocess(lat, output_type)
@@ -253,7 +255,7 @@ class LoraMultiConceptPipeline:
                       lora_list: Optional[Sequence[str]] = None, styleL: Optional[bool] = None, use_graph: bool = False,
                       trajectory: Optional[list] = None, fusion_start: int = FUSION_START, lora_mode: str = "merged",
                       controlnet=None, controlnet_image: Optional[torch.Tensor] = None, controlnet_conditioning_scale: float = 1.0,
-                      identitynet=None, identitynet_conditioning_scale: float = 1.0) -> torch.Tensor:
+                      identitynet=None, identitynet_conditioning_scale: float = 1.0, dedup: bool = False) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -263,7 +265,14 @@ class LoraMultiConceptPipeline:
         (lora_pipeline.py:519-536; ``controlnet2``/``t2i_image`` of instantid_pipeline.py:574-592).
         ``identitynet`` (InstantID, instantid_pipeline.py:638-674): ControlNet on the CONCEPT pass fed with the face tokens and
         the request's ``kps_image`` (1,3,H,W); requests then also carry ``region_image_embeds`` = [(2,16,Cx) [zero-id, id]] * K and
-        the UNet must have an :class:`omg_amd.ip_adapter.IPAdapter` installed."""
+        the UNet must have an :class:`omg_amd.ip_adapter.IPAdapter` installed.
+
+        ``dedup=True`` (OFF by default; SURVEY §7.4, "flag when used"): the reference duplicates the latents (:409) and is called
+        with two equal prompts, so until the first fused step the two samples of a request are the same computation twice
+        (stage 1: for the whole call).  With the batch-invariant kernels of this package those steps run ``[unc, cond]`` once per
+        request and write the result to both samples — bitwise the same latents as the full batch (tests/test_pipeline_gpu.py),
+        16 x 2 of the 336 sample-forwards of a 50-step stage-2 call fewer.  Used only where it is provably exact: equal prompt /
+        pooled / negative embeddings of the two samples, no controller or a pure-replacement one."""
         dev, dt = self.unet.device, self.unet.dtype
         n = len(requests)
         height = height or self.unet.config.sample_size * self.vae_scale_factor
@@ -312,6 +321,10 @@ class LoraMultiConceptPipeline:
                     ip_l.append(torch.cat([rie[c] for c in act], dim=0).to(device=dev, dtype=dt))
                     kps_l.append(r["kps_image"].to(device=dev, dtype=torch.float32))
         Ka = len(active)
+        twin = bool(dedup) and (controller is None or getattr(controller, "is_pure_replacement", False))
+        if twin:      # both samples of every request must be the same computation: [neg0, neg1, pos0, pos1] with equal halves
+            for e, tx in zip(ehs_l, text_l):
+                twin = twin and torch.equal(e[0], e[1]) and torch.equal(e[2], e[3]) and torch.equal(tx[0], tx[1]) and torch.equal(tx[2], tx[3])
         Hl, Wl = lats[0].shape[2:]
         fuse_possible = stage == 2 and Ka > 0 and S > fusion_start + 1
         nm, ncn = 4 * n, 2 * Ka * n                       # rows of the main block / the concept block
@@ -364,8 +377,10 @@ class LoraMultiConceptPipeline:
         # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
         key = (n, S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
                str(dt), batched, bool(styleL), tuple(lora_list), mshape, tuple(ehs.shape), id(controller), id(controlnet), id(identitynet),
-               float(controlnet_conditioning_scale), float(identitynet_conditioning_scale))
-        eng = self._engines.get(key)
+               float(controlnet_conditioning_scale), float(identitynet_conditioning_scale), twin)
+        eng = self._engines.pop(key, None)
+        if eng is not None:
+            self._engines[key] = eng                       # most recently used last
         if eng is None:
             eng = SimpleNamespace(graphs={}, warmed=set(), pool=None, coef=None)
             eng.lat = torch.empty((2 * n, Cl, Hl, Wl), dtype=torch.float32, device=dev)
@@ -384,6 +399,15 @@ class LoraMultiConceptPipeline:
                 eng.ehs_all = torch.empty((nb,) + tuple(ehs.shape[1:]), dtype=dt, device=dev)
                 eng.emb_all = torch.empty((S, nb, D), dtype=dt, device=dev)
                 eng.emb_cur_all = torch.empty((nb, D), dtype=dt, device=dev)
+            if twin:      # compact rows [unc, cond] per request for the steps in which the two samples coincide
+                eng.xin2 = torch.empty((2 * n, Cl, Hl, Wl), dtype=dt, device=dev)
+                eng.nout2 = torch.empty((2 * n, Cl, Hl, Wl), dtype=torch.float32, device=dev)
+                eng.ehs2 = torch.empty((2 * n,) + tuple(ehs.shape[1:]), dtype=dt, device=dev)
+                eng.emb_main2 = torch.empty((S, 2 * n, D), dtype=dt, device=dev)
+                eng.emb_cur2 = torch.empty((2 * n, D), dtype=dt, device=dev)
+                if use_cn:
+                    eng.cn_emb2 = torch.empty((S, 2 * n, D), dtype=dt, device=dev)
+                    eng.cn_emb_cur2 = torch.empty((2 * n, D), dtype=dt, device=dev)
             if use_cn:
                 eng.cn_image = torch.empty((controlnet_image.shape[0], 3, height, width), dtype=torch.float32, device=dev)
                 eng.cn_emb = torch.empty((S, nm, D), dtype=dt, device=dev)
@@ -393,8 +417,14 @@ class LoraMultiConceptPipeline:
                 eng.kps_all = torch.empty((n, 3, height, width), dtype=torch.float32, device=dev)
                 eng.idn_emb = torch.empty((S, ncn, D), dtype=dt, device=dev)
                 eng.idn_emb_cur = torch.empty((ncn, D), dtype=dt, device=dev)
-            if len(self._engines) >= 4:
-                self._engines.pop(next(iter(self._engines)))
+            while len(self._engines) >= self.max_engines:      # least recently used first; its captured graphs go with it
+                old_key = next(iter(self._engines))
+                self._engines.pop(old_key)
+                self.engine_evictions += 1
+                if self.engine_evictions in (1, 10, 100):
+                    import warnings
+                    warnings.warn(f"LoraMultiConceptPipeline: step engine evicted ({self.engine_evictions} so far): more than max_engines="
+                                  f"{self.max_engines} call shapes alternate and each eviction re-captures its hipGraphs; raise pipe.max_engines")
             self._engines[key] = eng
             # the key holds id()s: keep the objects alive so that an id cannot be recycled for a different object
             eng.refs = (controller, controlnet, identitynet, concept_models)
@@ -442,9 +472,22 @@ class LoraMultiConceptPipeline:
             t_all = ts.reshape(S, 1).expand(S, ncn).reshape(-1).contiguous()
             tids_c = self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev)
             eng.idn_emb.copy_(identitynet.time_embed(t_all, S * ncn, torch.cat(ctext_l, dim=0).repeat(S, 1), tids_c.repeat(S, 1)).view(S, ncn, D))
+        state_twin = None
+        if twin:
+            rows2 = torch.tensor([4 * j + r for j in range(n) for r in (0, 2)], dtype=torch.long, device=dev)      # unc0, cond0 of each request
+            eng.ehs2.copy_(ehs.index_select(0, rows2))
+            eng.emb_main2.copy_(emb_main.index_select(1, rows2))
+            if use_cn:
+                eng.cn_emb2.copy_(eng.cn_emb.index_select(1, rows2))
+            if main_slot >= 0:
+                state_twin = concept_models.lora_state([main_slot + 1] * (2 * n), merged=True) if merged else concept_models.lora_state([main_slot] * (2 * n), merged=False)
         if use_graph:
             # cached cross-attention K/V (and ControlNet conditioning features) must be refreshed eagerly:
             # replayed graphs read the stored tensors
+            if twin:
+                self.unet.refresh_cross_kv(eng.ehs2, state_twin)
+                if use_cn:
+                    controlnet.refresh_cross_kv(eng.ehs2)
             self.unet.refresh_cross_kv(eng.ehs, state_main)
             if batched:
                 self.unet.refresh_cross_kv(eng.ehs_all, state_all)
@@ -463,8 +506,34 @@ class LoraMultiConceptPipeline:
                 r0 = region_rows(j)
                 xin[r0: r0 + 2 * Ka].copy_(xin[4 * j + 3: 4 * j + 4].expand(2 * Ka, -1, -1, -1))
 
-        def step_body(fused: bool):
+        def twin_body():
+            """A step in which samples 0 and 1 of every request are still identical: one [unc, cond] forward per request, the noise
+            prediction written to both samples, then the ordinary CFG + scheduler step on all four rows."""
+            kw = dict(main_kw)
+            kw["omg_twin"] = True
+            x2, y2 = eng.xin2, eng.nout2
+            x2.view(n, 2, Cl, Hl, Wl).copy_(xin[:nm].view(n, 2, 2, Cl, Hl, Wl)[:, :, 0])
+            if use_cn:
+                ops.gather_step(eng.cn_emb2, step_idx, eng.cn_emb_cur2)
+                d_, m_ = controlnet(x2, None, encoder_hidden_states=eng.ehs2, controlnet_cond=eng.cn_image,
+                                    conditioning_scale=controlnet_conditioning_scale, emb=eng.cn_emb_cur2)
+                kw["omg_residuals"] = [(0, 2 * n, d_, m_)]
+            ops.gather_step(eng.emb_main2, step_idx, eng.emb_cur2)
+            self.unet.set_lora_state(state_twin)
+            try:
+                self.unet(x2, None, encoder_hidden_states=eng.ehs2, cross_attention_kwargs=kw, emb=eng.emb_cur2, out=y2)
+            finally:
+                self.unet.set_lora_state(None)
+            nout[:nm].view(n, 2, 2, Cl, Hl, Wl).copy_(y2.view(n, 2, 1, Cl, Hl, Wl).expand(n, 2, 2, Cl, Hl, Wl))
+            for j in range(n):
+                ops.fuse_cfg_step(nout[4 * j: 4 * j + 4], lat[2 * j: 2 * j + 2], coef, step_idx, guidance_scale=guidance_scale,
+                                  fuse=False, region_preds=[None] * K, masks=[None] * K,
+                                  model_input_next=xin[4 * j: 4 * j + 4], advance=(j == n - 1))
+
+        def step_body(fused: bool, twin_step: bool = False):
             """One denoising iteration; every per-step quantity is selected by the DEVICE step counter."""
+            if twin_step:
+                return twin_body()
             kw = dict(main_kw)
             residuals = []
             if use_cn:                                    # ControlNet on the main samples (lora_pipeline.py:519-536)
@@ -513,15 +582,16 @@ class LoraMultiConceptPipeline:
 
         def run_step(i: int):
             fused = fuse_possible and i > fusion_start
+            tw = twin and not fused          # the samples part ways at the first fused step (stage 1: never)
             if not use_graph:
-                step_body(fused)
+                step_body(fused, tw)
                 return
             if eng.epoch != pointer_epoch():          # a weight image or cached K/V the graphs point at was freed or re-allocated
                 eng.graphs.clear()
                 eng.warmed.clear()
                 eng.epoch = pointer_epoch()
             win = controller._self_window() if controller is not None and hasattr(controller, "_self_window") else None
-            regime = (fused, win)
+            regime = (fused, win, tw)
             g = eng.graphs.get(regime)
             if g is not None:
                 g.replay()
@@ -529,13 +599,13 @@ class LoraMultiConceptPipeline:
                     controller.cur_step += 1          # the replayed graph does not run the host-side counters
                 return
             if regime not in eng.warmed:              # first step of a regime runs eagerly (lazy inits, caches)
-                step_body(fused)
+                step_body(fused, tw)
                 eng.warmed.add(regime)
                 return
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g, pool=eng.pool):
-                step_body(fused)                      # records the step; host counters tick as in eager mode
+                step_body(fused, tw)                  # records the step; host counters tick as in eager mode
             if eng.pool is None:
                 eng.pool = g.pool()
             eng.graphs[regime] = g
@@ -573,7 +643,7 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                  controlnet_conditioning_scale: float = 1.0, t2i_controlnet_conditioning_scale: float = 1.0, controller=None,
                  concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None, region_masks=None,
                  region_prompt_embeds=None, region_image_embeds=None, output_type: str = "pil", return_dict: bool = True,
-                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, **kwargs):
+                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, dedup: bool = False, **kwargs):
         if prompt_embeds is None:
             raise L.OmgHipError("pass prompt_embeds=/pooled_prompt_embeds= (text encoders are outside this package's scope)")
         K = len(region_prompt_embeds or [])
@@ -590,7 +660,7 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                                  fusion_start=fusion_start, identitynet=self.controlnet if use_idn else None,
                                  identitynet_conditioning_scale=controlnet_conditioning_scale,
                                  controlnet=self.controlnet2 if t2i_image is not None else None, controlnet_image=t2i_image,
-                                 controlnet_conditioning_scale=t2i_controlnet_conditioning_scale)[0]
+                                 controlnet_conditioning_scale=t2i_controlnet_conditioning_scale, dedup=dedup)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         lat = self._postprocess(lat, output_type)

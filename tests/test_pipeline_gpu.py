@@ -192,6 +192,67 @@ def test_generate_many_equals_single_requests(dev):
             assert torch.equal(many[j], singles[j]), f"request {j} (graph={use_graph}): max diff {(many[j] - singles[j]).abs().max().item()}"
 
 
+@pytest.mark.parametrize("styleL", [False, True])
+def test_dedup_of_identical_samples_is_bitwise_equal_to_the_full_batch(dev, styleL):
+    """SURVEY §7.4 / VERDICT r2 item 5: until the first fused step (stage 1: always) samples 0 and 1 of a call are the same
+    computation; ``dedup=True`` runs [unc, cond] once per request in those steps.  Every step's latents must equal the full
+    [unc0, unc1, cond0, cond1] run bit for bit — eager and through captured graphs, one request and two in lock-step — and the
+    controller's counters must end where the full run leaves them.  A call whose two prompts differ must not be deduplicated."""
+    dtype = torch.float16
+    cfg, ocfg, sd, unet = setup(dev, dtype)
+    L = cfg.sample_size
+    S, gs, fstart = 8, 7.5, 3
+    H = W = L * 8
+    names = ou.lora_target_names(ocfg)
+    bank = LoraBank(unet, [LoraAdapter(nm, {k: (a.to(dev), b.to(dev)) for k, (a, b) in ou.make_lora(ocfg, names, 8, 100 + c, 0.8, dtype)[0].items()})
+                           for c, nm in enumerate(["c0", "c1", "style"])])
+    concept = ConceptModels(unet, bank)
+    pctl = pc.AttentionReplace([P, P], S, {"default_": 1.0}, 0.5, L // 4, L // 4, device=dev)
+    revise_regionally_controlnet_forward(unet, pctl)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
+    m1 = torch.zeros(H, W); m1[H // 4:, : W // 2] = 1
+    m2 = torch.zeros(H, W); m2[H // 4:, W // 2 - 16:] = 1
+
+    def request(seed, differ=False):
+        pe1, pp1 = embeds(cfg, 1, seed, dtype); ne1, np1 = embeds(cfg, 1, seed + 50, dtype)
+        pe = pe1.repeat(2, 1, 1)
+        if differ:
+            pe = pe.clone(); pe[1, 3] += 0.25
+        regions = []
+        for c in range(2):
+            re_, rp_ = embeds(cfg, 2, seed + 10 + c, dtype)
+            regions.append((re_[0:1], re_[1:2], rp_[0:1], rp_[1:2]))
+        return dict(prompt_embeds=pe, negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
+                    negative_pooled_prompt_embeds=np1.repeat(2, 1), region_prompt_embeds=regions, region_masks=[m1, m2],
+                    latents=torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(seed)))
+
+    def run(reqs, stage, dedup, use_graph):
+        pctl.reset()
+        traj = []
+        pipe.generate_many(reqs, height=H, width=W, num_inference_steps=S, guidance_scale=gs, cross_attention_kwargs={"scale": 0.8},
+                           controller=pctl, concept_models=concept, stage=stage, lora_list=["c0", "c1"], styleL=styleL, trajectory=traj,
+                           fusion_start=fstart, use_graph=use_graph, dedup=dedup)
+        assert (pctl.cur_step, pctl.cur_att_layer) == (S, 0)
+        return torch.stack([t.cpu() for t in traj])
+
+    one, two = [request(1)], [request(1), request(2)]
+    for stage in (2, 1):
+        full = run(one, stage, False, False)
+        assert torch.equal(run(one, stage, True, False), full), f"stage {stage}: eager dedup differs"
+        assert torch.equal(run(one, stage, True, True), full), f"stage {stage}: dedup through graphs differs (capture)"
+        assert torch.equal(run(one, stage, True, True), full), f"stage {stage}: dedup through graphs differs (replay)"
+        full2 = run(two, stage, False, False)
+        assert torch.equal(full2[:, 0], full)
+        assert torch.equal(run(two, stage, True, True), full2), f"stage {stage}: two requests"
+        if stage == 2:      # the samples do part ways after the first fused step, and stay together before it
+            assert torch.equal(full[fstart, 0], full[fstart, 1]) and not torch.equal(full[-1, 0], full[-1, 1])
+    # different prompts for the two samples: dedup must fall back to the full batch by itself
+    diff = [request(3, differ=True)]
+    assert torch.equal(run(diff, 2, True, False), run(diff, 2, False, False))
+    d = run(diff, 2, False, False)
+    assert not torch.equal(d[0, 0], d[0, 1])
+
+
 @pytest.mark.parametrize("lora_mode", ["merged", "segment"])
 def test_style_lora_runs_on_the_main_pass_too(dev, lora_mode):
     """styleL (inference_lora.py:162-164, :253-254): the style LoRA is loaded into the MAIN pipe as well, so every main forward
