@@ -130,11 +130,14 @@ class _Components:
         return [self.unet, self.vae, self.text_encoder, self.text_encoder_2]
 
 
-_CACHE: Dict[Tuple[str, str, Optional[str]], _Components] = {}
+_CACHE: Dict[Tuple[str, str], _Components] = {}
 
 
 def _components(path: str, dtype: torch.dtype, variant: Optional[str]) -> _Components:
-    key = (os.path.realpath(path), str(dtype), variant)
+    """One set of modules per (directory, dtype).  ``variant`` only chooses which file the FIRST load reads: diffusers' variants of a
+    directory are the same weights stored at another precision, and the reference's scripts mix them (inference_instantid.py:187-201
+    loads the main pipe with variant="fp16" and the concept pipe without) while the step engine needs ONE UNet behind both pipes."""
+    key = (os.path.realpath(path), str(dtype))
     if key not in _CACHE:
         _CACHE[key] = _Components(path, dtype, variant)
     return _CACHE[key]
@@ -228,8 +231,10 @@ class StableDiffusionXLPipeline(_PipeMixin, ConceptModels):
                                           adapters=comp.bank.adapters)
 
     @classmethod
-    def from_pretrained(cls, path: str, torch_dtype: torch.dtype = torch.float16, variant: Optional[str] = None, **kw):
-        return cls(_components(path, torch_dtype, variant))
+    def from_pretrained(cls, path: str, torch_dtype: torch.dtype = torch.float16, variant: Optional[str] = None, controlnet=None, **kw):
+        pipe = cls(_components(path, torch_dtype, variant))
+        pipe.controlnet = controlnet      # inference_instantid.py:196-201 hands the concept pipe an IdentityNet it never uses; kept for `.to`
+        return pipe
 
     def encode_prompt(self, prompt, prompt_2=None, device=None, num_images_per_prompt: int = 1, do_classifier_free_guidance: bool = True,
                       negative_prompt=None, negative_prompt_2=None, lora_scale: Optional[float] = None, **kw):

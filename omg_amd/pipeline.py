@@ -158,11 +158,12 @@ class LoraMultiConceptPipeline:
         ids = list(original_size) + list(crops) + list(target_size)
         return torch.tensor([ids] * n, dtype=torch.float32, device=device)
 
-    def _all_step_embeddings(self, ts: torch.Tensor, text: torch.Tensor, tids: torch.Tensor) -> torch.Tensor:
-        """emb[i] for every step in one batched pass: (S, B, 4*C0).  Depends only on (t_i, pooled text, time ids)."""
+    def _all_step_embeddings(self, ts: torch.Tensor, text: torch.Tensor, tids: torch.Tensor, unet=None) -> torch.Tensor:
+        """emb[i] for every step in one batched pass: (S, B, 4*C0).  Depends only on (t_i, pooled text, time ids) and on the
+        embedding layers of the UNet that will consume it (``unet``: the concept pipe's, when it is not the main one)."""
         S, B = ts.numel(), text.shape[0]
         t_all = ts.reshape(S, 1).expand(S, B).reshape(-1).contiguous()
-        emb = self.unet.time_embed(t_all, S * B, text.repeat(S, 1), tids.repeat(S, 1))
+        emb = (unet or self.unet).time_embed(t_all, S * B, text.repeat(S, 1), tids.repeat(S, 1))
         return emb.view(S, B, -1)
 
     # ------------------------------------------------------------------ the reference's call signature
@@ -361,9 +362,13 @@ class LoraMultiConceptPipeline:
             slots = [s for _ in range(n) for s in range(Ka) for _ in range(2)] if bank is not None else [-1] * ncn
             c_ehs = torch.cat(cehs_l, dim=0).contiguous()                                           # (2Ka*n, 77, Cx)
             emb_conc = self._all_step_embeddings(ts, torch.cat(ctext_l, dim=0),
-                                                 self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev))
+                                                 self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev),
+                                                 unet=getattr(concept_models, "_unet", None))
         merged = bank is not None and bank.mode == "merged"
-        batched = fuse_possible and (bank is None or merged)
+        # one batched forward needs ONE UNet behind both pipes (omg_amd.compat shares it; hand-built ConceptModels may not)
+        c_unet = getattr(concept_models, "_unet", self.unet) if concept_models is not None else self.unet
+        shared = c_unet is self.unet
+        batched = fuse_possible and (bank is None or merged) and shared
         if use_graph and not (bank is None or merged) and (fuse_possible or main_slot >= 0):
             raise L.OmgHipError("use_graph needs lora_mode='merged' (segment-mode K/V projections are not pointer-stable)")
         use_cn = controlnet is not None
@@ -371,7 +376,8 @@ class LoraMultiConceptPipeline:
         if use_cn and controlnet_image is None:
             raise ValueError("controlnet needs controlnet_image")
         if use_idn and not batched:
-            raise L.OmgHipError("identitynet runs in the batched (merged / no-LoRA) mode only")
+            raise L.OmgHipError("identitynet runs in the batched mode only: merged / no LoRA, and concept_models built on the pipeline's own "
+                                "UNet (omg_amd.compat's from_pretrained shares it between the main and the concept pipe)")
         mshape = tuple(masks_l[0][active[0]].shape) if active else (0, 0)
         D = emb_main.shape[-1]
         # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape

@@ -54,7 +54,9 @@ def write_tokenizer(folder):
     return len(vocab), vocab["<|endoftext|>"]
 
 
-def write_sdxl_dir(root, seed=0):
+def write_sdxl_dir(root, seed=0, plain_copies=False):
+    """``plain_copies``: also provide every weight file without the ``.fp16`` variant infix (a real SDXL directory holds both; the
+    InstantID script loads its concept pipe without ``variant=``)."""
     from omg_amd.text_encoder import ClipTextConfig, ClipTextEncoder
     from omg_amd.unet import UNet2DConditionModel
     from omg_amd.vae import AutoencoderKLDecoder, VaeConfig
@@ -88,6 +90,9 @@ def write_sdxl_dir(root, seed=0):
         save_file(sd, os.path.join(root, sub, "model.fp16.safetensors"))
     os.makedirs(os.path.join(root, "scheduler"))
     json.dump({"_class_name": "EulerDiscreteScheduler"}, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    if plain_copies:
+        for sub, stem in (("unet", "diffusion_pytorch_model"), ("vae", "diffusion_pytorch_model"), ("text_encoder", "model"), ("text_encoder_2", "model")):
+            os.link(os.path.join(root, sub, stem + ".fp16.safetensors"), os.path.join(root, sub, stem + ".safetensors"))
     return root
 
 

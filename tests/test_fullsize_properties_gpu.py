@@ -109,3 +109,26 @@ def test_sdxl_unet_is_batch_invariant_at_full_size(dev):
     both = fwd(0, 2)
     assert both.shape == (2, 4, Ls, Ls) and torch.isfinite(both).all()
     assert torch.equal(both[0:1], fwd(0, 1)) and torch.equal(both[1:2], fwd(1, 2))
+    # ---- the SAME full-size forward against the oracle: every one of the 4 x 128 x 128 outputs of
+    # sample 0, fp32 CPU restatement on the same fp16-rounded weights and inputs (~45 s of host time on the GPU box's cores)
+    from oracle import unet as ou
+    ocfg = ou.UNetConfig.sdxl()
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items() if k in ou.param_shapes(ocfg)}
+    assert len(sd) == len(ou.param_shapes(ocfg))
+    with torch.no_grad():
+        ref = ou.unet_forward(sd, ocfg, x[0:1].cpu(), 981, ctx[0:1].float().cpu(), te[0:1].float().cpu(), tid[0:1].cpu())
+    got = both[0:1].float().cpu()
+    rms = ref.pow(2).mean().sqrt().item()
+    e_max, e_rms = (got - ref).abs().max().item() / rms, (got - ref).pow(2).mean().sqrt().item() / rms
+    print(f"full-size SDXL UNet forward (2.57 B parameters, 1024^2, fp16) vs the fp32 oracle: max|d|/rms = {e_max:.3e}, rms(d)/rms = {e_rms:.3e} (output rms {rms:.3f})")
+    import json, os
+    try:
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "r03_fullsize_forward_vs_oracle.json"), "w") as f:
+            json.dump({"what": "one full-size SDXL UNet sample-forward (B=1 row of a B=2 batch, latent 128x128, t=981, fp16 storage) vs oracle/unet.py in fp32 on the CPU, "
+                               "all 65536 outputs", "max_abs_over_rms": e_max, "rms_err_over_rms": e_rms, "output_rms": rms}, f)
+    except OSError:
+        pass
+    # 70 transformer blocks and 17 resnet blocks of fp16 storage: measured + margin (profiles/r03_fullsize_forward_vs_oracle.json)
+    assert e_max < 6e-2 and e_rms < 1.5e-2, (e_max, e_rms)

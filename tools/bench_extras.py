@@ -5,7 +5,11 @@
   instantid  BASELINE configs[2]: OMG + InstantID, 2 identities, 1024^2, 30 Euler steps, guidance 3.0: IdentityNet (ControlNet)
              on every concept pass + IP-Adapter cross-attention with 16 face tokens
 
-python tools/bench_extras.py ips|both|instantid [--steps K] [--dtype fp16|fp8]   -> one JSON line per measurement
+  config4  BASELINE configs[4]: OMG + ControlNet (openpose-sdxl architecture, on the main pass of every step) + 3 concepts + style LoRA
+           (main pass, and [0.7, 0.5] with each concept), 1024^2, 50 DDIM steps; --dtype fp8 = the config's arithmetic (MX-fp8 on the
+           UNet's transformer Linears and resnet convolutions; the ControlNet stays fp16): 3.337 PFLOP per image
+
+python tools/bench_extras.py ips|both|instantid|config4 [--steps K] [--dtype fp16|fp8]   -> one JSON line per measurement
 """
 import argparse, contextlib, io, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +21,7 @@ from omg_amd.synthetic import c2_inputs, c2_masks, make_concept_models
 from omg_amd.unet import UNet2DConditionModel, UNetConfig
 
 ap = argparse.ArgumentParser()
-ap.add_argument("what", choices=["ips", "both", "instantid"])
+ap.add_argument("what", choices=["ips", "both", "instantid", "config4"])
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp8"])
 ap.add_argument("--ips", default="1,4,8")
@@ -26,6 +30,23 @@ dev, dt = torch.device("cuda:0"), torch.float16
 unet = UNet2DConditionModel(UNetConfig.sdxl(), dtype=dt, device=dev).init_synthetic_(seed=0)
 if a.dtype == "fp8":
     unet.set_linear_precision("mx8")
+    if a.what == "config4":
+        unet.set_conv_precision("mx8")
+
+
+def random_init_(module, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for name, p in module.named_parameters():
+        if name.endswith(".weight") and p.dim() >= 2:
+            w = torch.randn(p.shape, generator=g, device=dev) * p[0].numel() ** -0.5
+        elif name.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(p.shape, generator=g, device=dev)
+        else:
+            w = 0.1 * torch.randn(p.shape, generator=g, device=dev)
+        p.data.copy_(w.to(p.dtype))
+    module.invalidate_packed()
+    return module
+
 P = "a man and a woman walking on the street"
 ctl = pc.AttentionReplace([P, P], 50, {"default_": 1.0}, 0.4, 32, 32, device=dev, dtype=dt)
 with contextlib.redirect_stdout(io.StringIO()):
@@ -84,20 +105,44 @@ if a.what in ("ips", "both"):
         print(json.dumps({"measurement": "stage1_plus_stage2", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec, "sec_per_step": sec,
                           "workload": "BASELINE configs[1]: stage 1 (50 plain steps, decode) + stage 2 (fusion for i > 15, decode) per image; "
                                       "detection / segmentation between the stages excluded; 3.626 PFLOP per image (SURVEY 8d)", "steps_timed": a.steps}), flush=True)
+elif a.what == "config4":
+    from omg_amd.controlnet import ControlNetModel
+    cn = random_init_(ControlNetModel(UNetConfig.sdxl(), dtype=dt, device=dev), 7)
+    concept = make_concept_models(unet, n_concepts=3, rank=64, style=True)
+    pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
+    m3 = torch.zeros(1024, 1024, device=dev); m3[128:512, 300:700] = 1
+    masks3 = masks + [m3]
+    n = int(a.ips.split(",")[-1])
+    pose = torch.rand(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(9))
+
+    def reqs4(i):
+        out = []
+        for j in range(n):
+            r = c2_inputs(unet, seed=i * 16 + j, n_concepts=3)
+            r["region_masks"] = masks3
+            out.append(r)
+        return out
+
+    def run4(i):
+        ctl.reset()
+        lat = pipe.generate_many(reqs4(i), height=1024, width=1024, num_inference_steps=50, guidance_scale=7.5, cross_attention_kwargs={"scale": 0.8},
+                                 controller=ctl, concept_models=concept, stage=2, lora_list=["concept0", "concept1", "concept2"], styleL=True,
+                                 controlnet=cn, controlnet_image=pose, controlnet_conditioning_scale=1.0, use_graph=True)
+        for j in range(n):
+            vae.decode_latents(lat[j])
+        assert torch.isfinite(lat).all()
+    sec = timed(run4, a.steps)
+    pf = 3.337
+    print(json.dumps({"measurement": "config4", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec, "sec_per_step": sec,
+                      "end_to_end_tflops": pf * 1e3 * n / sec,
+                      "workload": "BASELINE configs[4]: SDXL 1024^2, 50 DDIM steps, ControlNet (openpose-sdxl architecture, 1.25 B parameters) on the main pass, 3 concepts "
+                                  "with overlapping masks, style LoRA on the main pass and [0.7, 0.5] with each concept LoRA, stage-2 call + upcast VAE decode; "
+                                  "3.337 PFLOP per image (SURVEY 8d); fp8 = MX-fp8 on the UNet's transformer Linears + resnet convolutions, ControlNet fp16",
+                      "steps_timed": a.steps}), flush=True)
 else:
     from omg_amd.controlnet import ControlNetModel
     from omg_amd.ip_adapter import IPAdapter
-    idn = ControlNetModel(UNetConfig.sdxl(), dtype=dt, device=dev)
-    g = torch.Generator(device=dev).manual_seed(5)
-    for name, p in idn.named_parameters():
-        if name.endswith(".weight") and p.dim() >= 2:
-            w = torch.randn(p.shape, generator=g, device=dev) * p[0].numel() ** -0.5
-        elif name.endswith(".weight"):
-            w = 1.0 + 0.1 * torch.randn(p.shape, generator=g, device=dev)
-        else:
-            w = 0.1 * torch.randn(p.shape, generator=g, device=dev)
-        p.data.copy_(w.to(p.dtype))
-    idn.invalidate_packed()
+    idn = random_init_(ControlNetModel(UNetConfig.sdxl(), dtype=dt, device=dev), 5)
     IPAdapter(unet, num_tokens=16, scale=0.8).init_synthetic_(seed=3)
     pipe = LoraMultiConceptPipeline(unet, make_scheduler("euler"))
     concept = ConceptModels(unet, None)
