@@ -38,167 +38,6 @@ struct AttnP {
   char* O; long ldo, o_bs;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnP p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], Vt[2]
-  using V8 = typename Vec<T>::v8;
-  using V4 = typename Vec<T>::v4;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int bq = p.qk_src ? p.qk_src[b] : b;       // batch supplying Q and K
-  const int q0 = blockIdx.x * QB + w * 32;
-  int q = q0 + l31;
-  const bool qvalid = q < p.Nq;
-  if (!qvalid) q = p.Nq - 1;
-
-  // Q fragments: B operand, lane (n = q, k-octet = hi) for each 16-wide d step
-  V8 qf[4];
-  {
-    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
-  }
-
-  // staging coordinates: thread -> (row, 16-B chunk), two passes of 32 rows
-  const int srow = tid >> 3, schunk = tid & 7;
-  const char* kbase = p.K + ((long)bq * p.k_bs + h * 64) * 2;
-  const char* vbase = p.Vt + ((long)(b * p.heads + h) * 64) * (long)p.Nkv_pad * 2;
-  u32x4 hk[2], hv[2];
-  auto load_tile = [&](int kv0) {
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int row = ps * 32 + srow;
-      const int key = kv0 + row;
-      u32x4 z = {0u, 0u, 0u, 0u};
-      hk[ps] = (key < p.Nkv) ? *(const u32x4*)(kbase + ((long)key * p.ldk + schunk * 8) * 2) : z;
-      hv[ps] = *(const u32x4*)(vbase + ((long)row * p.Nkv_pad + kv0 + schunk * 8) * 2);
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int row = ps * 32 + srow;
-      const int off = row * 128 + ((schunk ^ ((row >> 1) & 7)) << 4);
-      *(u32x4*)(smem + buf * TILE + off) = hk[ps];
-      *(u32x4*)(smem + (2 + buf) * TILE + off) = hv[ps];
-    }
-  };
-
-  f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  const int ntiles = (p.Nkv + KVB - 1) / KVB;
-  load_tile(0);
-  store_tile(0);
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    const int kv0 = t * KVB;
-    __syncthreads();
-    if (t + 1 < ntiles) load_tile(kv0 + KVB);
-    const char* kt = smem + buf * TILE;
-    const char* vt = smem + (2 + buf) * TILE;
-
-    // ---- S^T = K · Q^T : two 32-key tiles
-    f32x16 s[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[i][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int kc = ks * 2 + hi;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = i * 32 + l31;
-        V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-        s[i] = Vec<T>::mfma32(kf, qf[ks], s[i]);
-      }
-    }
-    // ---- mask the key tail (last tile only)
-    if (kv0 + KVB > p.Nkv) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key >= p.Nkv) s[i][r] = -1e30f;
-        }
-    }
-    // ---- online softmax (row = this lane's query; the other 16+16 keys live in lane^32)
-    float mt = s[0][0];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[i][r]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);
-    m_run = m_new;
-    const float mb = m_new * p.scale_log2e;
-    float psum = 0.f;
-    V8 pf[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(s[i][r] * p.scale_log2e - mb);
-        psum += e;
-        pf[i][r >> 3][r & 7] = (T)e;
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-
-    // ---- O^T += V^T · P^T : A = V^T (row d, keys in P's order), B = P
-#pragma unroll
-    for (int i = 0; i < 2; ++i)        // 32-key tile
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) { // 16-key k-step
-        const int c0 = i * 4 + k2 * 2 + hi;  // omg_transpose_v stores each 16-key group as [keys 0-3, 8-11 | 4-7, 12-15]: chunk c0 is this lane half's 8 keys
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int row = dt * 32 + l31;
-          const V8 vf = *(const V8*)(vt + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
-          o[dt] = Vec<T>::mfma32(vf, pf[i][k2], o[dt]);
-        }
-      }
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
-  }
-
-  // ---- finish: combine the two half-rows' sums, normalise, store
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = p.out_scale / l_tot;
-  if (qvalid) {
-    char* op = p.O + ((long)b * p.o_bs + (long)q * p.ldo + h * 64) * 2;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = dt * 32 + 8 * g + 4 * hi;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = o[dt][g * 4 + e] * inv;
-        V4* dst = (V4*)(op + d * 2);
-        if (p.accumulate) {
-          V4 old = *dst;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
-        }
-        V4 out;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = (T)v[e];
-        *dst = out;
-      }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // v2: the same tiling with the softmax's VALU work roughly halved (at head_dim 64 the 16 MFMAs of a 64-key tile are 512 cycles
 // per wave while the v1 softmax issued ~240 VALU instructions, ~1100 cycles: the kernel was VALU-bound at 0.25 of the MFMA peak).
@@ -703,7 +542,7 @@ AttnP make_params(const omg_attn_args* a) {
   return p;
 }
 
-int g_attn_variant = 0;      // 0 = heuristic (v3 / v2 by key count), 3 = v3 (64 query rows per wave, LDS-DMA staging), 2 = v2, 1 = v1; tools / A-B tests only
+int g_attn_variant = 0;      // 0 = heuristic (v3 / v2 by key count), 3 = v3 (64 query rows per wave, LDS-DMA staging), 2 = v2; tools / A-B tests only
 
 }  // namespace
 
@@ -719,10 +558,7 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   AttnP p = make_params(a);
   dim3 grid((a->Nq + QB - 1) / QB, a->heads, a->B);
   hipStream_t s = (hipStream_t)stream;
-  if (g_attn_variant == 1) {
-    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel<f16>, grid, dim3(256), 0, s, p);
-    else OMG_LAUNCH(attn_fwd_kernel<bf16>, grid, dim3(256), 0, s, p);
-  } else if (g_attn_variant == 3 || (g_attn_variant == 0 && a->Nkv > 128)) {   // heuristic: v3 for self-attention, v2 for the 77 / 93 / 16-key cross calls (one or two tiles: latency-bound, v3's 256-row blocks only add to it)
+  if (g_attn_variant == 3 || (g_attn_variant == 0 && a->Nkv > 128)) {   // heuristic: v3 for self-attention, v2 for the 77 / 93 / 16-key cross calls (one or two tiles: latency-bound, v3's 256-row blocks only add to it)
     dim3 grid3((a->Nq + 255) / 256, a->heads, a->B);
     if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel3<f16>, grid3, dim3(256), 0, s, p);
     else OMG_LAUNCH(attn_fwd_kernel3<bf16>, grid3, dim3(256), 0, s, p);

@@ -8,17 +8,17 @@
 // output pixel (b,y,x) and tap (dy,dx) is 128 contiguous bytes of the input.
 //
 // Kernels in this file (chosen per launch by choose_variant; every one produces the same bits for the same problem):
-//   v1 (gemm_kernel)      128x128x64 tile, 4 waves of 64x64, two blocks per CU — small launches, narrow outputs.
-//   v5 (gemm_kernel_v5)   256x{256,128}x64, 8 waves in two staggered groups — fallback for the LoRA second K-segment.
-//   v6 (gemm_kernel_v6)   same tiles, LDS-DMA issued between MFMA quartets through buffer descriptors; 256x128 in use.
+//   v1 (gemm_kernel)      128x128x64 tile, 4 waves of 64x64, two blocks per CU — small launches, narrow outputs, and everything
+//                         the large-tile kernels do not take (the LoRA second K-segment, K % 64 != 0, operands >= 2 GiB).
+//   v6 (gemm_kernel_v6)   256x{256,128}x64 on eight waves, LDS-DMA issued between MFMA quartets through buffer descriptors; 256x128 in use.
 //   v7 (gemm_kernel_v7)   256x256 (and 128x320 for the convs of width 320 k) on FOUR waves, 128x128 per wave, K loop
 //                         software-pipelined inside the wave, one barrier per stage — the workhorse (>= 70 % of the time).
-//   v8 (gemm_kernel_v8)   v7 as a persistent kernel (debug variant 16, not selected yet).
+// (Round 3 removed v5 — the eight-wave predecessor of v6 — and v8, a persistent form of v7 that spilled: DESIGN.md §5.)
 // Common to all: v_mfma_f32_32x32x16, tiles staged global->LDS with LDS-DMA (1 KiB per wave instruction) into a
 // double-buffered, XOR-swizzled image — the DMA destination is lane-linear, so the swizzle is applied to the per-lane
 // SOURCE chunk and again on the ds_read_b128 (cdna guide §5.4 rule 21); out-of-image taps and the K tail read zeros
-// (a global zero page in v1/v5, out-of-range buffer offsets in v6-v8).  v1/v5 stage the fp32 accumulators through LDS for
-// row-coalesced stores; v6-v8 accumulate the transposed tile and store 16 bytes per lane straight from registers
+// (a global zero page in v1, out-of-range buffer offsets in v6 / v7).  v1 stages the fp32 accumulators through LDS for
+// row-coalesced stores; v6 / v7 accumulate the transposed tile and store 16 bytes per lane straight from registers
 // (epilogue_direct).  Measurements and the rejected alternatives: DESIGN.md §5.
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -315,321 +315,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Large-tile kernels (v5 .. v8): 256-row block tiles, LDS stages of BK = 64 filled by LDS-DMA, raw s_barrier + explicit
+// Large-tile kernels (v6, v7): 256-row block tiles, LDS stages of BK = 64 filled by LDS-DMA, raw s_barrier + explicit
 // s_waitcnt instead of __syncthreads.  LDS image per stage: rows of 128 B (8 chunks of 16 B), chunk ^= (row >> 1) & 7,
 // applied on the DMA source side and on the fragment read.
-// Row-coalesced epilogue shared by the large-tile kernels: one 32-row slab of every wave per pass through a
-// [32][NT*32 + 4] fp32 staging area in LDS (bias / per-sample bias / SiLU / GEGLU / residual applied on 16-byte rows).
-// The wave's tile is (MT*32) x (NT*32) at (wm0, wn0) = (m0 + wm*MT*32, n0 + wn*NT*32).
-template <typename T, int MT, int NT = 2>
-OMG_DEV void epilogue_slabs(const GemmP& p, f32x16 (&acc)[MT][NT], char* smem, int w, int lane, int m0, int n0, int wm, int wn,
-                            int m_end) {
-  constexpr int LD = NT * 32 + 4;                  // 68 (== STAGE_LD) or 132 floats
-  constexpr int LPR = NT * 4;                      // lanes per 16-byte-chunked row (8 or 16)
-  constexpr int RPP = 64 / LPR;                    // rows per pass (8 or 4)
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int wm0 = m0 + wm * (MT * 32);
-  const int wn0 = n0 + wn * (NT * 32);
-  float* stage = (float*)smem + w * (32 * LD);
-  const int sub = lane % LPR, rsub = lane / LPR;
-  const int gc = wn0 + sub * 8;
-  const bool geglu = p.act == OMG_ACT_GEGLU;
-  const bool gb_rows = p.group_bias != nullptr && !fold_group_bias(p);
-  // The staging area is private to the wave: LDS executes one wave's instructions in order, so a compiler-level fence
-  // between the slab's writes and its reads is all the synchronisation needed (the caller has already joined the block
-  // after the K loop).  Block barriers here would re-serialise the two staggered wave groups eight times per tile.
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        stage[row * LD + j * 32 + l31] = acc[i][j][r];
-      }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (geglu) {
-      // every 64-column block is [32 values | 32 gates] (ops.geglu_row_perm): a lane takes 8 values + their 8 gates
-      constexpr int GL = NT * 2;                   // lanes per row (4 or 8)
-      constexpr int GR = 64 / GL;                  // rows per pass (16 or 8)
-      const int s4 = lane % GL, r4 = lane / GL;
-      const int blk = s4 >> 2, c8 = (s4 & 3) * 8;  // 64-column block of the wave tile, value column inside it
-#pragma unroll
-      for (int it = 0; it < 32 / GR; ++it) {
-        const int row = it * GR + r4;
-        const int gm = wm0 + i * 32 + row;
-        const int gcc = wn0 + blk * 64 + c8;
-        if (gm < m_end && gcc < p.N) {
-          float v[8], g[8];
-          const float* sp = stage + row * LD + blk * 64 + c8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { v[e] = sp[e]; g[e] = sp[32 + e]; }
-          float o[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = v[e] * gelu_f(g[e]) * p.out_scale;
-          *(u32x4*)(p.C + ((long)gm * p.ldc + ((wn0 + blk * 64) >> 1) + c8) * 2) = pack8<T>(o);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 32 / RPP; ++it) {
-        const int row = it * RPP + rsub;
-        const int gm = wm0 + i * 32 + row;
-        if (gm < m_end && gc < p.N) {
-          float v[8];
-          const float* sp = stage + row * LD + sub * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = sp[e];
-          if (gb_rows) {
-            float gb[8];
-            const int g = gm / p.rows_per_group;
-            unpack8<T>(*(const u32x4*)(p.group_bias + ((long)g * p.ldgb + gc) * 2), gb);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += gb[e];
-          }
-          if (p.act == OMG_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
-          }
-          if (p.residual) {
-            float rv[8];
-            unpack8<T>(*(const u32x4*)(p.residual + ((long)gm * p.ldr + gc) * 2), rv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(v[e], p.out_scale, rv[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-          }
-          *(u32x4*)(p.C + ((long)gm * p.ldc + gc) * 2) = pack8<T>(v);
-        }
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// v5: BK = 64 double-buffered large-tile kernel (the fallback of v6/v7 for the LoRA second K-segment and K % 64 != 0).
-// Its predecessor used a 4-deep ring of BK = 32 stages; phase timing showed the 4 LDS-DMA instructions of such a stage cost
-// ~650 cycles per wave against 512 cycles of MFMA: a 64-byte row is half a cache line, so every DMA instruction touched 16
-// lines for 1 KiB.  With 128-byte rows each instruction moves 8 WHOLE lines.
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
-__global__ __launch_bounds__(WM_ * WN_ * 64, 2) void gemm_kernel_v5(GemmP p) {
-  constexpr int BK3 = 64;          // 128-byte rows = whole cache lines per DMA row
-  constexpr int NW = WM_ * WN_;
-  constexpr int MT = BM_ / WM_ / 32;             // 32-row MFMA tiles per wave (2 or 4)
-  constexpr int NT = BN_ / WN_ / 32;             // must be 2
-  static_assert(NT == 2, "wave tile N must be 64");
-  constexpr int A_BYTES = BM_ * BK3 * 2;
-  constexpr int STAGE_BYTES = (BM_ + BN_) * BK3 * 2;
-  constexpr int A_INSTR = BM_ / 8 / NW;          // one DMA instruction = 8 rows x 128 B
-  constexpr int B_INSTR = BN_ / 8 / NW;
-  static_assert(A_INSTR >= 1 && B_INSTR >= 1, "tile too small for the wave count");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-
-  const int nwg = gridDim.x;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tiles_per_group = p.tiles_m * p.tiles_n;
-  const int grp = bid / tiles_per_group;
-  const int t_in = bid - grp * tiles_per_group;
-  // grouped ordering: 8 M-tiles x all N-tiles per group, M fastest inside the group, so that the ~32 consecutive
-  // tiles an XCD receives touch ~8 A panels + <= 4..5 W panels instead of 32 + 1 (tall-skinny GEMMs re-read A per N tile)
-  int tm, tn;
-  {
-    const int per_group = 8 * p.tiles_n;
-    const int gid = t_in / per_group;
-    const int first_m = gid * 8;
-    const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
-    const int r = t_in - gid * per_group;
-    tm = first_m + (r % gsz);
-    tn = r / gsz;
-  }
-  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
-  const int m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
-  const int m0 = m_base + tm * BM_;
-  const int n0 = tn * BN_;
-
-  int adapter = 0;
-  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
-  const bool seg2 = (p.K2 > 0) && (adapter >= 0);
-  if (p.w_adapter_stride != 0 && adapter < 0) return;
-  const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
-  const char* W2p = p.W2 + (seg2 ? (long)adapter * p.w2_adapter_stride * 2 : 0);
-  const int a2off = (p.a2_col_block > 0) ? (n0 / p.a2_col_block) * p.K2 : 0;
-
-  const int nk1 = (p.K + BK3 - 1) / BK3;
-  const int nk2 = seg2 ? (p.K2 + BK3 - 1) / BK3 : 0;
-  const int nk = nk1 + nk2;
-
-  // ---- staging coordinates.  DMA instruction j of an operand covers rows [j*16, j*16+16); wave w issues
-  // instructions j = w + i*NW.  lane -> (row = lane>>2, 16-B position = lane&3).
-  const int prow = lane >> 3;
-  const int ppos = lane & 7;
-  const char* zero = (const char*)omg_zero_page;
-  const char* a_ptr[A_INSTR];      // plain GEMM: row base of A (segment 1) incl. source chunk
-  const char* a2_ptr[A_INSTR];
-  const char* w_ptr[B_INSTR];
-  const char* w2_ptr[B_INSTR];
-  int a_chunk[A_INSTR], w_chunk[B_INSTR];
-  int cb[A_INSTR], cy[A_INSTR], cx[A_INSTR];
-#pragma unroll
-  for (int i = 0; i < A_INSTR; ++i) {
-    const int r = (w + i * NW) * 8 + prow;
-    int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;
-    const int c = ppos ^ ((r >> 1) & 7);
-    a_chunk[i] = c;
-    if constexpr (CONV) {
-      const int hw = p.Hout * p.Wout;
-      const int b = gm / hw; const int rem = gm - b * hw;
-      cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;
-      a_ptr[i] = nullptr; a2_ptr[i] = nullptr;
-    } else {
-      a_ptr[i] = p.A + ((long)gm * p.lda + c * 8) * 2;
-      a2_ptr[i] = p.A2 ? p.A2 + ((long)gm * p.lda2 + a2off + c * 8) * 2 : nullptr;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < B_INSTR; ++i) {
-    const int r = (w + i * NW) * 8 + prow;
-    int gn = n0 + r; if (gn > p.N - 1) gn = p.N - 1;
-    const int c = ppos ^ ((r >> 1) & 7);
-    w_chunk[i] = c;
-    w_ptr[i] = Wp + ((long)gn * p.ldw + c * 8) * 2;
-    w2_ptr[i] = p.W2 ? W2p + ((long)gn * p.ldw2 + c * 8) * 2 : nullptr;
-  }
-  const int Ctot = p.C1 + p.C2;
-  const int cpt = CONV ? Ctot / BK3 : 1;
-  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
-
-  auto issue = [&](int kt) {
-    char* sbase = smem + (kt & 1) * STAGE_BYTES;
-    const bool s2 = kt >= nk1;
-    const int k0 = (s2 ? kt - nk1 : kt) * BK3;
-    const int Kseg = s2 ? p.K2 : p.K;
-    const bool full = (k0 + BK3) <= Kseg;              // wave-uniform: no per-lane K-tail test needed
-    if constexpr (CONV) {
-      const int tap = kt / cpt; const int cc = kt - tap * cpt;
-      const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
-      int c0 = cc * BK3;
-      const char* xsrc = p.A; int xC = p.C1;
-      if (c0 >= p.C1) { xsrc = p.X2; xC = p.C2; c0 -= p.C1; }
-      const int Hl = p.upsample ? p.Hin * 2 : p.Hin;
-      const int Wl = p.upsample ? p.Win * 2 : p.Win;
-#pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        int iy = cy[i] * p.stride + dy - pad;
-        int ix = cx[i] * p.stride + dx - pad;
-        const bool ok = (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
-        if (p.upsample) { iy >>= 1; ix >>= 1; }
-        const long pix = ((long)cb[i] * p.Hin + iy) * p.Win + ix;
-        const char* asrc = ok ? xsrc + (pix * xC + c0 + a_chunk[i] * 8) * 2 : zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < B_INSTR; ++i) {
-        const char* wsrc = w_ptr[i] + (long)kt * (BK3 * 2);
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_INSTR; ++i) {
-        const char* asrc = (s2 ? a2_ptr[i] : a_ptr[i]) + k0 * 2;
-        if (!full && (k0 + a_chunk[i] * 8) >= Kseg) asrc = zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)asrc, (lds_ptr_t)(sbase + (w + i * NW) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < B_INSTR; ++i) {
-        const char* wsrc = (s2 ? w2_ptr[i] : w_ptr[i]) + k0 * 2;
-        if (!full && (k0 + w_chunk[i] * 8) >= Kseg) wsrc = zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)(sbase + A_BYTES + (w + i * NW) * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  const int wm = w / WN_, wn = w % WN_;
-  f32x16 acc[MT][NT];
-  acc_init_cols<T, MT, NT>(p, acc, lane & 31, n0 + wn * (NT * 32), m0);
-  using V8 = typename Vec<T>::v8;
-
-  // stage-relative fragment offsets (ks = 0/1 differ by chunk ^ 2 -> precompute both)
-  int aro[MT][4], bro[NT][4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int kc = ks * 2 + hi;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int ra = wm * (MT * 32) + i * 32 + l31;
-      aro[i][ks] = ra * 128 + ((kc ^ ((ra >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int rb = wn * 64 + j * 32 + l31;
-      bro[j][ks] = A_BYTES + rb * 128 + ((kc ^ ((rb >> 1) & 7)) << 4);
-    }
-  }
-
-  issue(0);
-
-  // Double-buffered BK=64 stages (2 x 64 KiB for the 256x256 tile) + two-group stagger at half-stage granularity:
-  //   early waves: DMA(kt+1), read half 0, MFMA half 0, read half 1, MFMA half 1
-  //   late  waves: MFMA half 1 of stage kt-1, DMA(kt+1), read half 0, MFMA half 0, read half 1
-  // so on every SIMD one wave is in an 8-MFMA x2 section while its partner issues DMA / fragment reads.
-  const bool late = w >= NW / 2;
-  V8 af[2][MT], bf[2][NT];
-  auto mma = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = Vec<T>::mfma32(af[ks][i], bf[ks][j], acc[i][j]);
-  };
-  auto rd = [&](const char* sb, int half) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[ks][j] = *(const V8*)(sb + bro[j][half * 2 + ks]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[ks][i] = *(const V8*)(sb + aro[i][half * 2 + ks]);
-    }
-  };
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_vmcnt<0>();                       // DMA(kt) was issued one stage ago; nothing newer is in flight
-    __builtin_amdgcn_s_barrier();
-    if (late && kt > 0) mma();
-    if (kt + 1 < nk) issue(kt + 1);
-    const char* sb = smem + (kt & 1) * STAGE_BYTES;
-    rd(sb, 0);
-    mma();
-    rd(sb, 1);
-    if (!late) mma();
-  }
-  if (late) mma();
-  __syncthreads();
-  epilogue_slabs<T, MT>(p, acc, smem, w, lane, m0, n0, wm, wn, m_end);
-}
-
 // conv A-operand byte offset of one output pixel's tap inside the (logical, possibly 2x-upsampled) input image;
 // out-of-image taps get an offset beyond the buffer's num_records, which the buffer load turns into zeros
 OMG_DEV int conv_voff(int b, int oy, int ox, int ch_bytes, int stride, int dy, int dx, int Hl, int Wl, int ups, int Hin, int Win,
                       int pix_bytes, int c0_bytes) {
+  // branch-free on purpose: with `&&` hipcc put two exec-mask regions (s_and_saveexec + s_cbranch_execz) round the address of
+  // EVERY A-operand DMA inside the MFMA loop; one unsigned compare per axis and a select instead
   int iy = oy * stride + dy, ix = ox * stride + dx;
-  const bool ok = (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
-  if (ups) { iy >>= 1; ix >>= 1; }
+  const bool ok = ((unsigned)iy < (unsigned)Hl) & ((unsigned)ix < (unsigned)Wl);
+  iy >>= ups; ix >>= ups;
   const int pix = (b * Hin + iy) * Win + ix;
-  return ok ? pix * pix_bytes + c0_bytes + ch_bytes : 0x7ffffff0;
+  const int off = pix * pix_bytes + c0_bytes + ch_bytes;
+  return ok ? off : 0x7ffffff0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -897,6 +597,14 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 
   const bool ts_on = (p.dbg & 16) && blockIdx.x < 8192 && threadIdx.x == 0;
   long long ts0 = 0, ts1 = 0, ts2 = 0;
+  // tools only (dbg bits 16..23 = S in units of 0.25 us): de-phase the CUs.  Every block of the launch's first round waits a
+  // pseudo-random share of S before it starts; a CU takes its next block when the previous one ends, so the offsets persist and
+  // the per-tile bursts (first-stage fetch, C-tile stores) of the 256 CUs no longer hit the memory system at the same instant.
+  if (((p.dbg >> 16) & 0xff) != 0 && blockIdx.x < 256) {
+    const long long wait = (long long)((blockIdx.x * 97) & 255) * ((p.dbg >> 16) & 0xff) * 25 / 256;      // 10 ns ticks
+    const long long t_end = __builtin_amdgcn_s_memrealtime() + wait;
+    while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(2);
+  }
   if (p.dbg & 16) ts0 = __builtin_amdgcn_s_memrealtime();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -971,7 +679,6 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 
   const int wm = w >> 1, wn = w & 1;
   f32x16 acc[MT][NT];
-  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * (NT * 32));
   using V8 = typename Vec<T>::v8;
   // fragment i of k-step ks sits at aoff[ks] + i * 4096 (32 rows further: same swizzle term)
   int aoff[4], boff[4];
@@ -1069,6 +776,8 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   // prologue: stage 0 completely, the A half of stage 1, the first fragments
   OMG_PREP(0);
   OMG_DMAN(0, AB + WB, smem);
+  // the bias loads ride behind the first stage's DMA (their latency used to sit in front of it: ~1 us of every tile)
+  const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * (NT * 32));
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   if (p.dbg & 16) ts1 = __builtin_amdgcn_s_memrealtime();
@@ -1128,247 +837,9 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// v8: v7 made persistent.  One block per CU walks tiles t = blockIdx.x, + gridDim.x, ... (same tile -> XCD map as the
-// one-block-per-tile launch).  After the K loop of a tile — once past the last stage barrier nobody reads LDS any
-// more — the wave sets up the NEXT tile and issues its first TWO stages (32 LDS-DMA instructions) before it starts the
-// epilogue of the current tile: the 3.8 us prologue (first-stage latency) and the 0.6 us block hand-over of v7 disappear
-// under the 5.6 us epilogue, and the loads are ahead of the epilogue's 128 KB of stores in the CU's memory pipeline.
-// Same arithmetic, same bits as every other variant.
-template <typename T, bool CONV>
-__global__ __launch_bounds__(256, 1) void gemm_kernel_v8(GemmP p) {
-  constexpr int BM_ = 256, BN_ = 256, BKc = 64, MT = 4, NT = 4;
-  constexpr int A_BYTES = BM_ * BKc * 2;
-  constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
-  const int l31 = lane & 31;
-
-  const int tiles_per_group = p.tiles_m * p.tiles_n;
-  const int total = p.tile_groups * tiles_per_group;
-  const int nk = (p.K + BKc - 1) / BKc;
-  const int Ctot = p.C1 + p.C2;
-  const long a_bytes = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C1 * 2 : ((long)(p.M - 1) * p.lda + p.K) * 2;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(a_bytes < 0x7fffff00 ? a_bytes : 0x7fffff00), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(CONV && p.X2 ? p.X2 : p.A), 0,
-      CONV ? (int)((long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * p.C2 * 2) : 0, 0x00020000);
-  const long w_bytes = ((long)(p.N - 1) * p.ldw + p.K) * 2;
-
-  const int prow = lane >> 3, ppos = lane & 7;
-  const int dchunk = (ppos ^ ((w & 1) * 4 + (prow >> 1))) * 16;
-  const int ldo = w * 1024;
-  const int wm = w >> 1, wn = w & 1;
-  using V8 = typename Vec<T>::v8;
-  int aoff[4], boff[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int sw = ((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-    aoff[ks] = (wm * 128 + l31) * 128 + sw;
-    boff[ks] = A_BYTES + (wn * 128 + l31) * 128 + sw;
-  }
-  int koff = 0;
-  int tap_dy = 0, tap_dx = 0, c0b = 0, xCb = 0;
-  bool x2 = false;
-  const int cpt = CONV ? Ctot / BKc : 1;
-  const int pad = CONV ? (p.ksize == 3 ? 1 : 0) : 0;
-  const int Hl = CONV ? (p.upsample ? p.Hin * 2 : p.Hin) : 0;
-  const int Wl = CONV ? (p.upsample ? p.Win * 2 : p.Win) : 0;
-
-  // ---- state of the tile whose loads are being issued
-  int m0 = 0, n0 = 0, m_end = 0, tile = 0;
-  bool more = false;
-  __amdgpu_buffer_rsrc_t rsW = rsA;
-  // Plain GEMM: row block i of a wave is 32 rows further (no clamping: rows past the matrix end are out of the buffer's
-  // range and read as zeros, rows of the next group only feed accumulator rows the epilogue never stores), so one VGPR
-  // offset per operand plus an SGPR step replaces the 16 per-tile offsets of v7; the conv keeps its pixel coordinates.
-  int voffA0 = 0, voffW0 = 0;
-  const int stepA = CONV ? 0 : (int)(32 * p.lda * 2), stepW = (int)(32 * p.ldw * 2);
-  int cb[8], cy[8], cx[8];
-  // first tile >= t_ (stepping by the grid) whose group has a weight slot; `more` says whether there is one
-#define OMG_TILE(t_)                                                                                       \
-  do {                                                                                                     \
-   tile = (t_);                                                                                            \
-   for (;;) {                                                                                              \
-    more = tile < total;                                                                                   \
-    if (!more) break;                                                                                      \
-    int bid_;                                                                                              \
-    {                                                                                                      \
-      const int q = total >> 3, r = total & 7, xcd = tile & 7, idx = tile >> 3;                              \
-      bid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                \
-    }                                                                                                      \
-    const int grp = bid_ / tiles_per_group;                                                                \
-    const int t_in = bid_ - grp * tiles_per_group;                                                         \
-    int tm, tn;                                                                                            \
-    {                                                                                                      \
-      const int per_group = 8 * p.tiles_n;                                                                 \
-      const int gid = t_in / per_group;                                                                    \
-      const int first_m = gid * 8;                                                                         \
-      const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;                               \
-      const int r = t_in - gid * per_group;                                                                \
-      tm = first_m + (r % gsz);                                                                            \
-      tn = r / gsz;                                                                                        \
-    }                                                                                                      \
-    const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;                                   \
-    m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;                                         \
-    m0 = m_base + tm * BM_;                                                                                \
-    n0 = tn * BN_;                                                                                         \
-    int adapter = 0;                                                                                       \
-    if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];                                        \
-    if (p.w_adapter_stride != 0 && adapter < 0) { tile += (int)gridDim.x; continue; }                      \
-    const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);         \
-    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, (int)w_bytes, 0x00020000);                       \
-    {                                                                                                      \
-      const int r0 = w * 8 + prow;                                                                         \
-      voffW0 = (int)((long)(n0 + r0) * p.ldw * 2) + dchunk;                                                \
-      if constexpr (!CONV) voffA0 = (int)((long)(m0 + r0) * p.lda * 2) + dchunk;                           \
-    }                                                                                                      \
-    if constexpr (CONV) {                                                                                  \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                      \
-        const int r = (w + i * 4) * 8 + prow;                                                              \
-        int gm = m0 + r; if (gm > m_end - 1) gm = m_end - 1;                                               \
-        const int hw = p.Hout * p.Wout;                                                                    \
-        const int b = gm / hw; const int rem = gm - b * hw;                                                \
-        cb[i] = b; cy[i] = rem / p.Wout; cx[i] = rem - cy[i] * p.Wout;                                     \
-      }                                                                                                    \
-    }                                                                                                      \
-    break;                                                                                                 \
-   }                                                                                                       \
-  } while (0)
-#define OMG_PREP(kt_)                                                                                      \
-  do {                                                                                                     \
-    koff = (kt_) * (BKc * 2);                                                                              \
-    if constexpr (CONV) {                                                                                  \
-      const int tap = (kt_) / cpt; const int cc = (kt_) - tap * cpt;                                       \
-      tap_dy = tap / p.ksize - pad; tap_dx = tap - (tap / p.ksize) * p.ksize - pad;                        \
-      int c0 = cc * BKc;                                                                                   \
-      x2 = c0 >= p.C1;                                                                                     \
-      if (x2) c0 -= p.C1;                                                                                  \
-      c0b = c0 * 2; xCb = (x2 ? p.C2 : p.C1) * 2;                                                          \
-    }                                                                                                      \
-  } while (0)
-#define OMG_DMA(d_, nb_)                                                                                   \
-  do {                                                                                                     \
-    if ((d_) < 8) {                                                                                        \
-      const int i_ = (d_) & 7;                                                                             \
-      if (CONV) dma16(x2 ? rsA2 : rsA, (nb_) + ldo + i_ * 4096,                                            \
-                      conv_voff(cb[i_], cy[i_], cx[i_], dchunk, p.stride, tap_dy, tap_dx, Hl, Wl, p.upsample, p.Hin, p.Win, xCb, c0b), 0); \
-      else dma16(rsA, (nb_) + ldo + i_ * 4096, voffA0, koff + i_ * stepA);                                         \
-    } else {                                                                                               \
-      const int i_ = (d_) & 7;                                                                             \
-      dma16(rsW, (nb_) + A_BYTES + ldo + i_ * 4096, voffW0, koff + i_ * stepW);                                      \
-    }                                                                                                      \
-  } while (0)
-#define OMG_DMA16(nb_)                                                                                     \
-  do { _Pragma("unroll") for (int d_ = 0; d_ < 16; ++d_) OMG_DMA(d_, nb_); } while (0)
-  // first two stages of the tile just set up (both LDS buffers are free)
-#define OMG_PROLOGUE()                                                                                     \
-  do {                                                                                                     \
-    OMG_PREP(0); OMG_DMA16(smem);                                                                          \
-    if (nk > 1) { OMG_PREP(1); OMG_DMA16(smem + STAGE_BYTES); }                                            \
-  } while (0)
-#define OMG_RD(f_, sb_, ks_)                                                                               \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j) bf[f_][j] = *(const V8*)((sb_) + boff[ks_] + j * 4096); \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i) af[f_][i] = *(const V8*)((sb_) + aoff[ks_] + i * 4096); \
-  } while (0)
-#define OMG_RD1(f_, sb_, ks_, r_)                                                                          \
-  do {                                                                                                     \
-    const bool isA_ = (r_) == 1 || (r_) >= 5;                                                              \
-    const int idx_ = (r_) == 0 ? 0 : (r_) == 1 ? 0 : (r_) <= 4 ? (r_) - 1 : (r_) - 4;                      \
-    if (!isA_) bf[f_][idx_] = *(const V8*)((sb_) + boff[ks_] + idx_ * 4096);                               \
-    else af[f_][idx_] = *(const V8*)((sb_) + aoff[ks_] + idx_ * 4096);                                     \
-  } while (0)
-#define OMG_MM1(f_, n_) acc[(n_) >> 2][(n_) & 3] = Vec<T>::mfma32(bf[f_][(n_) & 3], af[f_][(n_) >> 2], acc[(n_) >> 2][(n_) & 3])
-#define OMG_KSTEP(f_, RD_, rb_, rks_, DMA_, d0_, db_)                                                      \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) {                                                     \
-      OMG_MM1(f_, 2 * s_);                                                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if ((RD_) == 1) OMG_RD1(1 - (f_), rb_, rks_, s_);                                                    \
-      if ((RD_) == 2 && s_ < 4) { OMG_RD1(1 - (f_), rb_, rks_, 2 * s_); OMG_RD1(1 - (f_), rb_, rks_, 2 * s_ + 1); } \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-      OMG_MM1(f_, 2 * s_ + 1);                                                                             \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if (DMA_) OMG_DMA((d0_) + s_, db_);                                                                  \
-      __builtin_amdgcn_sched_barrier(0);                                                                   \
-    }                                                                                                      \
-  } while (0)
-  // one stage (see v7); W0_ = false for the first stage of a tile, whose successor was loaded whole by the prologue
-#define OMG_STAGE(HAS1_, HAS2_, W0_)                                                                       \
-  do {                                                                                                     \
-    const char* cur = smem + (kt & 1) * STAGE_BYTES;                                                       \
-    char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;                                                       \
-    OMG_KSTEP(0, 1, cur, 1, (HAS1_) && (W0_), 8, nxt);                                                     \
-    OMG_KSTEP(1, 1, cur, 2, false, 0, nxt);                                                                \
-    OMG_KSTEP(0, 1, cur, 3, false, 0, nxt);                                                                \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                            \
-    __builtin_amdgcn_s_barrier();                                                                          \
-    if (HAS2_) OMG_PREP(kt + 2);                                                                           \
-    OMG_KSTEP(1, (HAS1_) ? 2 : 0, nxt, 0, HAS2_, 0, (char*)cur);                                           \
-  } while (0)
-
-  f32x16 acc[MT][NT];
-  V8 af[2][MT], bf[2][NT];
-  OMG_TILE((int)blockIdx.x);
-  if (!more) return;
-  OMG_PROLOGUE();
-  for (;;) {
-    const bool gb_epi = acc_init_bias<T, MT, NT>(p, acc, lane, m0, n0 + wn * 128);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    OMG_RD(0, smem, 0);
-    int kt = 0;
-    if (nk == 1) OMG_STAGE(false, false, false);
-    else if (nk == 2) OMG_STAGE(true, false, false);
-    else OMG_STAGE(true, true, false);
-    kt = 1;
-    for (; kt < nk - 2; ++kt) OMG_STAGE(true, true, true);
-    if (kt < nk - 1) { OMG_STAGE(true, false, true); ++kt; }
-    if (kt < nk) OMG_STAGE(false, false, true);
-    const int e_m0 = m0, e_n0 = n0, e_mend = m_end;
-    OMG_TILE(tile + (int)gridDim.x);
-    if (more) OMG_PROLOGUE();
-    epilogue_direct<T, MT, NT>(p, acc, lane, e_m0 + wm * 128, e_n0 + wn * 128, e_mend, gb_epi);
-    if (!more) break;
-  }
-#undef OMG_TILE
-#undef OMG_PREP
-#undef OMG_DMA
-#undef OMG_DMA16
-#undef OMG_PROLOGUE
-#undef OMG_RD
-#undef OMG_RD1
-#undef OMG_MM1
-#undef OMG_KSTEP
-#undef OMG_STAGE
-}
-
 bool g_use_glds = true;
 int g_dbg = 0;
-int g_variant = 0;   // 0 = heuristic; 1 = 128x128 v1; 11/12 = v5 256x256 / 256x128; 13/14 = v6; 15 = v7 256x256; 16 = v8; 24 = v7 128x320; 25 = v7 256x256 with the transposed streaming epilogue
-
-template <typename T, bool CONV, int BM_, int BN_, int WM_, int WN_>
-int launch_v5(GemmP p, hipStream_t s, int mrows) {
-  constexpr int ring = 2 * (BM_ + BN_) * 64 * 2;
-  constexpr int epi = WM_ * WN_ * 32 * STAGE_LD * 4;
-  constexpr int lds = ring > epi ? ring : epi;
-  static bool attr = false;
-  if (!attr) {
-    attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v5<T, CONV, BM_, BN_, WM_, WN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
-  p.tiles_m = (mrows + BM_ - 1) / BM_;
-  p.tiles_n = (p.N + BN_ - 1) / BN_;
-  p.dbg = g_dbg;
-  const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
-  if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v5<T, CONV, BM_, BN_, WM_, WN_>), dim3(grid), dim3(WM_ * WN_ * 64), lds, s, p);
-  return omg_check_launch("gemm_v5");
-}
+int g_variant = 0;   // 0 = heuristic; 1 = 128x128 v1; 13/14 = v6 256x256 / 256x128; 15 = v7 256x256; 24 = v7 128x320; 25 = v7 256x256 with the transposed streaming epilogue
 
 template <typename T, bool CONV, int MT>
 int launch_v6(GemmP p, hipStream_t s, int mrows) {
@@ -1418,27 +889,8 @@ int num_cus() {
   return n;
 }
 
-template <typename T, bool CONV>
-int launch_v8(GemmP p, hipStream_t s, int mrows) {
-  constexpr int lds = 2 * (256 + 256) * 64 * 2;
-  static bool attr = false;
-  if (!attr) {
-    attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v8<T, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
-  p.tiles_m = (mrows + 255) / 256;
-  p.tiles_n = (p.N + 255) / 256;
-  p.dbg = g_dbg;
-  const int total = p.tile_groups * p.tiles_m * p.tiles_n;
-  if (total <= 0) return OMG_OK;
-  const int grid = total < num_cus() ? total : num_cus();
-  OMG_LAUNCH((gemm_kernel_v8<T, CONV>), dim3(grid), dim3(256), lds, s, p);
-  return omg_check_launch("gemm_v8");
-}
-
-// Tile choice from measured rates (profiles/r01_microbench_*.log): the staggered BK=64 256x256 kernel (v5) wins whenever it can put
-// >= ~120 tiles on the 256 CUs; below that the staggered 256x128 kernel if IT reaches ~120 tiles, else the 128x128
-// kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
+// Tile choice from measured rates (profiles/r01_microbench_*.log): a 256x256 tile wins whenever it can put >= ~120 tiles on the
+// 256 CUs; below that the 256x128 kernel if IT reaches ~120 tiles, else the 128x128 kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
 int choose_variant(int mrows, int groups, int N, bool conv) {
   if (g_variant != 0) return g_variant;
   const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
@@ -1471,10 +923,10 @@ int launch(const GemmP& p, hipStream_t s) {
     // the transposed streaming epilogue (25) is the default form of the 256x256 tile: +4..12 % (tools/xe_time.py); only the
     // short-K projections with a residual lose (the residual's scattered loads then share HBM with write-through stores)
     if (v == 15 && g_variant == 0 && !(p.residual != nullptr && p.K <= 640)) v = 25;
-    if (v == 24) { if (v6ok) return launch_v7<T, CONV, 0, 2, 5>(p, s, mrows); v = 12; }
-    if (v == 16) { if (v6ok) return launch_v8<T, CONV>(p, s, mrows); v = 11; }
-    if (v == 15) { if (v6ok) return launch_v7<T, CONV>(p, s, mrows); v = 11; }
-    if (v == 25) { if (v6ok) return launch_v7<T, CONV, 0, 4, 4, true>(p, s, mrows); v = 11; }
+    // what the large-tile kernels do not handle (!v6ok) falls through to the 128x128 kernel below
+    if (v == 24 && v6ok) return launch_v7<T, CONV, 0, 2, 5>(p, s, mrows);
+    if (v == 15 && v6ok) return launch_v7<T, CONV>(p, s, mrows);
+    if (v == 25 && v6ok) return launch_v7<T, CONV, 0, 4, 4, true>(p, s, mrows);
 #ifdef OMG_ABLATION_BUILDS   // make ABLATE=1: seven more instantiations of v7 for tools/gemm_ablate.py (3 minutes of compile time)
     if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
       if (v >= 17 && v <= 23 && v6ok) {
@@ -1490,9 +942,7 @@ int launch(const GemmP& p, hipStream_t s) {
       }
     }
 #endif
-    if (v == 13 || v == 14) { if (v6ok) return v == 13 ? launch_v6<T, CONV, 4>(p, s, mrows) : launch_v6<T, CONV, 2>(p, s, mrows); v = (v == 13) ? 11 : 12; }
-    if (v == 11) return launch_v5<T, CONV, 256, 256, 2, 4>(p, s, mrows);
-    if (v == 12) return launch_v5<T, CONV, 256, 128, 4, 2>(p, s, mrows);
+    if ((v == 13 || v == 14) && v6ok) return v == 13 ? launch_v6<T, CONV, 4>(p, s, mrows) : launch_v6<T, CONV, 2>(p, s, mrows);
   }
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
@@ -1513,10 +963,12 @@ void ensure_attrs() {
   (void)hipFuncSetAttribute((const void*)gemm_kernel<f16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)gemm_kernel<f16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)gemm_kernel<f16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#ifndef OMG_DEV_F16_ONLY
   (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)gemm_kernel<bf16, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#endif
 }
 
 }  // namespace
@@ -1566,7 +1018,12 @@ extern "C" int omg_gemm(const omg_gemm_args* a, void* stream) {
   p.tiles_m = (mrows + BM - 1) / BM;
   p.tiles_n = (a->N + BN - 1) / BN;
   hipStream_t s = (hipStream_t)stream;
+#ifdef OMG_DEV_F16_ONLY
+  OMG_REQUIRE(a->dtype == OMG_F16, "omg_gemm: this is a DEV=1 build (fp16 kernels only)");
+  return launch<f16, false>(p, s);
+#else
   return a->dtype == OMG_F16 ? launch<f16, false>(p, s) : launch<bf16, false>(p, s);
+#endif
 }
 
 extern "C" int omg_conv2d(const omg_conv2d_args* a, void* stream) {
@@ -1599,5 +1056,10 @@ extern "C" int omg_conv2d(const omg_conv2d_args* a, void* stream) {
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   if (a->group_bias) OMG_REQUIRE(a->ldgb % 8 == 0, "omg_conv2d: ldgb");
   hipStream_t s = (hipStream_t)stream;
+#ifdef OMG_DEV_F16_ONLY
+  OMG_REQUIRE(a->dtype == OMG_F16, "omg_conv2d: this is a DEV=1 build (fp16 kernels only)");
+  return launch<f16, true>(p, s);
+#else
   return a->dtype == OMG_F16 ? launch<f16, true>(p, s) : launch<bf16, true>(p, s);
+#endif
 }

@@ -70,8 +70,14 @@ OMG_DEV void swap_runs(unsigned (&q)[4]) {   // q[0..1] = run 0 (4 halves), q[2.
 // makes a load return zeros and a store vanish, so row / column predicates are a v_cndmask on the offset instead of an
 // exec-mask branch around every access, and there is no 64-bit address arithmetic per access.
 constexpr int EPI_OOB = 0x7f000000;
+// The descriptor words go through readfirstlane: built from kernel arguments they ARE wave-uniform, but hipcc kept them in VGPRs
+// inside the epilogue and wrapped EVERY buffer load / store in a waterfall loop (4 v_readfirstlane + compare + saveexec + branch:
+// ~900 loops in a v7 kernel, the 32 stores of a wave serialised one loop after the other — cdna guide T20).
 OMG_DEV __amdgpu_buffer_rsrc_t epi_rsrc(const char* base, long bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, base != nullptr ? (int)(bytes < 0x7effff00L ? bytes : 0x7effff00L) : 0, 0x00020000);
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane(base != nullptr ? (int)(bytes < 0x7effff00L ? bytes : 0x7effff00L) : 0);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
 }
 // 16 bytes at byte offset `off` (this lane's 8 consecutive columns) -> the 8 values in accumulator order (runs 0, 1)
 template <typename T>

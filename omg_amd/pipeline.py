@@ -256,7 +256,8 @@ class LoraMultiConceptPipeline:
                       lora_list: Optional[Sequence[str]] = None, styleL: Optional[bool] = None, use_graph: bool = False,
                       trajectory: Optional[list] = None, fusion_start: int = FUSION_START, lora_mode: str = "merged",
                       controlnet=None, controlnet_image: Optional[torch.Tensor] = None, controlnet_conditioning_scale: float = 1.0,
-                      identitynet=None, identitynet_conditioning_scale: float = 1.0, dedup: bool = False) -> torch.Tensor:
+                      identitynet=None, identitynet_conditioning_scale: float = 1.0, dedup: bool = False,
+                      concept_lora: bool = True) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -343,7 +344,8 @@ class LoraMultiConceptPipeline:
         # LoRA scale: the concept UNet is always called with cross_attention_kwargs={'scale': 0.8} (hard-coded, :592-598); the main UNet
         # (style slot) with the caller's cross_attention_kwargs (:546-566; PEFT's default scale is 1.0)
         main_scale = float((cross_attention_kwargs or {}).get("scale", 1.0))
-        bank = concept_models.bank if concept_models is not None else None
+        # InstantID's concepts are identities (IP-Adapter tokens + IdentityNet), not LoRA adapters: its `lora_list` only counts them
+        bank = concept_models.bank if (concept_models is not None and concept_lora) else None
         combos = []
         if fuse_possible:
             combos = [((lora_list[c], 0.7), ("style", 0.5)) if styleL else ((lora_list[c], 1.0),) for c in active]
@@ -595,6 +597,7 @@ class LoraMultiConceptPipeline:
             if eng.epoch != pointer_epoch():          # a weight image or cached K/V the graphs point at was freed or re-allocated
                 eng.graphs.clear()
                 eng.warmed.clear()
+                eng.pool = None                       # the pool dies with its last graph: a later capture must open a new one
                 eng.epoch = pointer_epoch()
             win = controller._self_window() if controller is not None and hasattr(controller, "_self_window") else None
             regime = (fused, win, tw)
@@ -666,7 +669,7 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                                  fusion_start=fusion_start, identitynet=self.controlnet if use_idn else None,
                                  identitynet_conditioning_scale=controlnet_conditioning_scale,
                                  controlnet=self.controlnet2 if t2i_image is not None else None, controlnet_image=t2i_image,
-                                 controlnet_conditioning_scale=t2i_controlnet_conditioning_scale, dedup=dedup)[0]
+                                 controlnet_conditioning_scale=t2i_controlnet_conditioning_scale, dedup=dedup, concept_lora=False)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         lat = self._postprocess(lat, output_type)

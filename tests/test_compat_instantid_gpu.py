@@ -289,4 +289,4 @@ def test_instantid_driver_code_runs_on_the_compat_objects(dev, hub_dirs, use_pos
     image3 = sample_image(pipe, input_prompt=swapped, concept_models=pipe_concepts, input_neg_prompt=["painting"] * len(input_prompt),
                           generator=torch.Generator(device).manual_seed(seed), controller=controller, face_app=face_app, image=face_kps, stage=2,
                           controlnet_conditioning_scale=idn_rate, region_masks=[mask1, mask2], guidance_scale=cfg_scale, num_inference_steps=S, **kwargs)
-    assert np.abs(np.array(image3[1]).astype(int) - b1).max() > 1
+    assert not np.array_equal(np.array(image3[1]), np.array(image2[1]))

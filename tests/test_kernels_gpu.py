@@ -310,7 +310,7 @@ def test_gemm_variants_are_bitwise_identical(dev, dtype):
     try:
         lib.omg_debug_set_gemm_variant(1)
         base = run_all()
-        for v in (11, 12, 13, 14, 15, 16, 24, 25):
+        for v in (13, 14, 15, 24, 25):
             lib.omg_debug_set_gemm_variant(v)
             for k, (o, r) in enumerate(zip(run_all(), base)):
                 assert torch.equal(o, r), f"variant {v} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"

@@ -242,15 +242,15 @@ def test_dedup_of_identical_samples_is_bitwise_equal_to_the_full_batch(dev, styl
         assert torch.equal(run(one, stage, True, True), full), f"stage {stage}: dedup through graphs differs (capture)"
         assert torch.equal(run(one, stage, True, True), full), f"stage {stage}: dedup through graphs differs (replay)"
         full2 = run(two, stage, False, False)
-        assert torch.equal(full2[:, 0], full)
+        assert torch.equal(full2[:, 0:1], full)
         assert torch.equal(run(two, stage, True, True), full2), f"stage {stage}: two requests"
         if stage == 2:      # the samples do part ways after the first fused step, and stay together before it
-            assert torch.equal(full[fstart, 0], full[fstart, 1]) and not torch.equal(full[-1, 0], full[-1, 1])
+            assert torch.equal(full[fstart, 0, 0], full[fstart, 0, 1]) and not torch.equal(full[-1, 0, 0], full[-1, 0, 1])
     # different prompts for the two samples: dedup must fall back to the full batch by itself
     diff = [request(3, differ=True)]
     assert torch.equal(run(diff, 2, True, False), run(diff, 2, False, False))
     d = run(diff, 2, False, False)
-    assert not torch.equal(d[0, 0], d[0, 1])
+    assert not torch.equal(d[0, 0, 0], d[0, 0, 1])
 
 
 @pytest.mark.parametrize("lora_mode", ["merged", "segment"])

@@ -15,7 +15,8 @@ dev = torch.device("cuda:0")
 x = torch.randn(M, K, device=dev, dtype=torch.float16)
 w = torch.randn(N, K, device=dev, dtype=torch.float16)
 out = torch.empty(M, N, device=dev, dtype=torch.float16)
-lib.omg_debug_set_gemm_variant(15 | ((16 | extra) << 8))
+var = int(sys.argv[5]) if len(sys.argv) > 5 else 15
+lib.omg_debug_set_gemm_variant(var | ((16 | extra) << 8))
 for _ in range(3):
     ops.gemm(x, w, out=out)
 torch.cuda.synchronize()
@@ -40,7 +41,7 @@ print(f"prologue (start -> stage 0 landed) {mean(pro)/100:.2f} us   main loop {m
       f"gap to next block on the slot {mean(gap)/100:.2f} us   kernel span {(max(r[3] for r in rows) - t_min)/100:.1f} us")
 k0 = sorted(cus)[0]
 print("one slot:", [(e[0], e[1], e[2], e[3]) for e in cus[k0][:6]])
-lib.omg_debug_set_gemm_variant(15 | (extra << 8))
+lib.omg_debug_set_gemm_variant(var | (extra << 8))
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ops.gemm(x, w, out=out)
 s.record()
