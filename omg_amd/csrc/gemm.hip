@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_v6(GemmP p) {
 // ABL (tools only, results are wrong): 1 = no LDS-DMA in the K loop, 2 = no fragment reads in the K loop, 4 = no wait / barrier
 // (MT, NT) = (4, 4): 256x256 tile.  (2, 5): 128x320 tile, wave tile 64x160 — for the layers whose width is 320 * k and
 // pads badly to 256 (N = 320: 512, N = 640: 768) or leaves a ragged last round (N = 1280 at M = 32768).
-template <typename T, bool CONV, int ABL = 0, int MT = 4, int NT = 4, bool XE = false>
+template <typename T, bool CONV, int ABL = 0, int MT = 4, int NT = 4, bool XE = false, int EF = 0>
 __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   constexpr int BM_ = MT * 64, BN_ = NT * 64, BKc = 64;
   constexpr int AB = MT * 2, WB = NT * 2;          // A / W row blocks (8 rows each) per wave per stage
@@ -828,7 +828,13 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
   }
   if (p.dbg & 16) ts2 = __builtin_amdgcn_s_memrealtime();
   // XE: 8 KB per wave behind the two stage buffers (other waves may still be reading the last stage)
-  epilogue_direct<T, MT, NT, XE>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * (NT * 32), m_end, gb_epi, smem + 2 * STAGE_BYTES + w * 8192);
+  if constexpr (EF == 2) {
+    // residual: staged through the stage buffers, which nobody reads after the loop's last barrier (this wave's 32 KB slice)
+    res_stage_dma(p, smem + w * 32768, lane, m0 + wm * 128, n0 + wn * 128, m_end);
+    epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * (NT * 32), m_end, gb_epi, smem + 2 * STAGE_BYTES + w * 8192,
+                                       smem + w * 32768);
+  } else
+  epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane, m0 + wm * (MT * 32), n0 + wn * (NT * 32), m_end, gb_epi, smem + 2 * STAGE_BYTES + w * 8192);
   if (ts_on) {
     long long* t = omg_dbg_ts[blockIdx.x];
     t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memrealtime();
@@ -861,21 +867,21 @@ int launch_v6(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v6");
 }
 
-template <typename T, bool CONV, int ABL = 0, int MT = 4, int NT = 4, bool XE = false>
+template <typename T, bool CONV, int ABL = 0, int MT = 4, int NT = 4, bool XE = false, int EF = 0>
 int launch_v7(GemmP p, hipStream_t s, int mrows) {
   constexpr int BM_ = MT * 64, BN_ = NT * 64;
   constexpr int lds = 2 * (BM_ + BN_) * 64 * 2 + (XE ? 4 * 8192 : 0);
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<T, CONV, ABL, MT, NT, XE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v7<T, CONV, ABL, MT, NT, XE, EF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + BM_ - 1) / BM_;
   p.tiles_n = (p.N + BN_ - 1) / BN_;
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v7<T, CONV, ABL, MT, NT, XE>), dim3(grid), dim3(256), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v7<T, CONV, ABL, MT, NT, XE, EF>), dim3(grid), dim3(256), lds, s, p);
   return omg_check_launch("gemm_v7");
 }
 
@@ -920,13 +926,20 @@ int launch(const GemmP& p, hipStream_t s) {
     const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim && c_sz < lim &&
                       (p.group_bias == nullptr || (long)(p.M / (p.rows_per_group > 0 ? p.rows_per_group : 1) + 1) * p.ldgb * 2 < lim);
     if (v == 24 && p.act == OMG_ACT_GEGLU) v = 15;      // a 160-wide wave tile cannot hold whole [32 value | 32 gate] blocks
-    // the transposed streaming epilogue (25) is the default form of the 256x256 tile: +4..12 % (tools/xe_time.py); only the
-    // short-K projections with a residual lose (the residual's scattered loads then share HBM with write-through stores)
-    if (v == 15 && g_variant == 0 && !(p.residual != nullptr && p.K <= 640)) v = 25;
+    // the transposed streaming epilogue (25) is the form of the 256x256 tile the heuristic uses: +2..12 % on every Linear / conv shape of the
+    // workload (tools/xe_time.py, tools/ksched_ab.py n640) — since the epilogue's descriptors are scalar also with a residual at K <= 640
+    if (v == 15 && g_variant == 0) v = 25;
     // what the large-tile kernels do not handle (!v6ok) falls through to the 128x128 kernel below
     if (v == 24 && v6ok) return launch_v7<T, CONV, 0, 2, 5>(p, s, mrows);
     if (v == 15 && v6ok) return launch_v7<T, CONV>(p, s, mrows);
-    if (v == 25 && v6ok) return launch_v7<T, CONV, 0, 4, 4, true>(p, s, mrows);
+    if (v == 25 && v6ok) {      // one kernel per epilogue form (gemm_epilogue.h, EF)
+      const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
+      if (p.act == OMG_ACT_GEGLU) return launch_v7<T, CONV, 0, 4, 4, true, 3>(p, s, mrows);
+      if (gb_rows || p.act == OMG_ACT_SILU) return launch_v7<T, CONV, 0, 4, 4, true, 4>(p, s, mrows);
+      if (p.residual != nullptr && !(g_dbg & 64)) return launch_v7<T, CONV, 0, 4, 4, true, 2>(p, s, mrows);
+      if (p.residual != nullptr) return launch_v7<T, CONV, 0, 4, 4, true, 0>(p, s, mrows);      // tools: register-direct residual (dbg 64)
+      return launch_v7<T, CONV, 0, 4, 4, true, 1>(p, s, mrows);
+    }
 #ifdef OMG_ABLATION_BUILDS   // make ABLATE=1: seven more instantiations of v7 for tools/gemm_ablate.py (3 minutes of compile time)
     if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
       if (v >= 17 && v <= 23 && v6ok) {

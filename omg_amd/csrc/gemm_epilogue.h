@@ -151,6 +151,7 @@ struct EpiCtx {
   int lane_col;                 // byte offset of the lane's unit (j = 0, pr = 0) inside a row
   int wn0, n_out;               // first output column of the wave tile / width of the output matrix
   char* xl;                     // XE: this wave's 8 KB of LDS for the row-block transposition
+  const char* rl;               // residual tile of this wave staged in LDS by LDS-DMA (res_stage_dma), or nullptr
   int voob[NT][2];              // 0 where the unit's columns are inside the matrix, EPI_OOB where they are not
 };
 
@@ -232,10 +233,11 @@ OMG_DEV void xe_flush(const GemmP& p, const EpiCtx<4>& cx, int i, int col0) {
   asm volatile("" ::: "memory");
 }
 // SiLU / per-row group bias / residual decided at run time inside the unit loop: the rare combinations
-template <typename T, int MT, int NT, bool RS, bool GENERIC, bool XE = false>
+template <typename T, int MT, int NT, bool RS, bool GENERIC, bool XE = false, bool RL = false>
 OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, bool has_gb) {
   const float osc = p.out_scale;
   const bool has_rs = GENERIC ? p.residual != nullptr : RS;
+  if constexpr (RL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged residual tile has landed (own DMAs, own LDS slice)
   u32x4 rraw[2][NT][2];         // residual of row block i: the lane's NT*2 16-byte units, fetched one row block ahead
 #define OMG_FETCH_RES(i_, buf_)                                                                            \
   do {                                                                                                     \
@@ -245,12 +247,12 @@ OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<N
       _Pragma("unroll") for (int pr = 0; pr < 2; ++pr)                                                     \
         rraw[buf_][j][pr] = __builtin_amdgcn_raw_buffer_load_b128(cx.rsR, ro_ | cx.voob[j][pr], (j * 32 + pr * 16) * 2, 0); \
   } while (0)
-  if (has_rs) OMG_FETCH_RES(0, 0);
+  if (has_rs && !RL) OMG_FETCH_RES(0, 0);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int gm = cx.wm0 + i * 32 + cx.l31;
     const bool row_ok = gm < cx.m_end;
-    if (has_rs && i + 1 < MT) OMG_FETCH_RES(i + 1, (i + 1) & 1);
+    if (has_rs && !RL && i + 1 < MT) OMG_FETCH_RES(i + 1, (i + 1) & 1);
     const int ro = row_ok ? gm * (int)p.ldc * 2 + cx.lane_col : EPI_OOB;
     const int go = GENERIC && has_gb && row_ok ? ((gm / p.rows_per_group) * (int)p.ldgb) * 2 + cx.lane_col : EPI_OOB;
 #pragma unroll
@@ -273,7 +275,9 @@ OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<N
           }
         }
         if (has_rs) {
-          const u32x4 rr = rraw[i & 1][j][pr];
+          // RL: the lane's 16 bytes (8 columns) of row l31 from the LDS image res_stage_dma wrote: 16-byte piece c of row r at position c ^ (r & 15)
+          const u32x4 rr = RL ? *(const u32x4*)(cx.rl + i * 8192 + cx.l31 * 256 + (((4 * j + 2 * pr + cx.hi) ^ (cx.l31 & 15)) << 4))
+                              : rraw[i & 1][j][pr];
           unsigned q[4] = {rr[0], rr[1], rr[2], rr[3]};
           swap_runs<T>(q);
           u32x4 sw = {q[0], q[1], q[2], q[3]};
@@ -323,10 +327,16 @@ OMG_DEV void epilogue_geglu(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<
   }
 }
 
-template <typename T, int MT, int NT, bool XE = false>
-OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0, int m_end, bool has_gb, char* xl = nullptr) {
+// EF = the ONE epilogue form compiled into the kernel: 0 = all of them behind run-time branches (small tiles, v6); 1 = bias only,
+// 2 = + residual staged in LDS (res_stage_dma), 3 = GEGLU, 4 = per-row group bias / SiLU / residual decided per unit at run time,
+// 5 = + residual by register-direct loads (kernels without a free LDS slice for the staging).
+// One form per kernel: with all forms behind run-time branches the 256-accumulator kernels spill inside the epilogue, and a scratch reload
+// there waits on vmcnt — i.e. on every store in flight (the 20 % residual penalty of round 2 was mostly that).
+template <typename T, int MT, int NT, bool XE = false, int EF = 0>
+OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int wm0, int wn0, int m_end, bool has_gb, char* xl = nullptr,
+                             const char* res_lds = nullptr) {
   static_assert(!XE || NT == 4, "the transposed epilogue is written for 128-column wave tiles");
-  const bool geglu = p.act == OMG_ACT_GEGLU;
+  const bool geglu = EF == 0 ? p.act == OMG_ACT_GEGLU : EF == 3;
   const int n_out = geglu ? p.N / 2 : p.N;
   EpiCtx<NT> cx;
   cx.hi = lane >> 5; cx.l31 = lane & 31; cx.wm0 = wm0; cx.m_end = m_end;
@@ -340,15 +350,27 @@ OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, in
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) cx.voob[j][pr] = (wn0 + j * 32 + pr * 16 + cx.hi * 8 < p.N && !(p.dbg & 1024)) ? 0 : EPI_OOB;   // dbg 1024 (tools): drop all stores
   cx.lane_col = (wn0 + cx.hi * 8) * 2;
-  cx.wn0 = wn0; cx.n_out = n_out; cx.xl = xl;
-  if (geglu) {
-    epilogue_geglu<T, MT, NT, XE>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);   // GEGLU output is half as wide
-  } else if (has_gb || p.act == OMG_ACT_SILU) {
+  cx.wn0 = wn0; cx.n_out = n_out; cx.xl = xl; cx.rl = res_lds;
+  if constexpr (EF == 1) {
+    epilogue_rows<T, MT, NT, false, false, XE>(p, acc, cx, false);
+  } else if constexpr (EF == 2) {
+    epilogue_rows<T, MT, NT, true, false, XE, true>(p, acc, cx, false);
+  } else if constexpr (EF == 3) {
+    epilogue_geglu<T, MT, NT, XE>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);
+  } else if constexpr (EF == 4) {
     epilogue_rows<T, MT, NT, false, true, XE>(p, acc, cx, has_gb);
-  } else if (p.residual != nullptr) {
+  } else if constexpr (EF == 5) {
     epilogue_rows<T, MT, NT, true, false, XE>(p, acc, cx, false);
   } else {
-    epilogue_rows<T, MT, NT, false, false, XE>(p, acc, cx, false);
+    if (geglu) {
+      epilogue_geglu<T, MT, NT, XE>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);   // GEGLU output is half as wide
+    } else if (has_gb || p.act == OMG_ACT_SILU) {
+      epilogue_rows<T, MT, NT, false, true, XE>(p, acc, cx, has_gb);
+    } else if (p.residual != nullptr) {
+      epilogue_rows<T, MT, NT, true, false, XE>(p, acc, cx, false);
+    } else {
+      epilogue_rows<T, MT, NT, false, false, XE>(p, acc, cx, false);
+    }
   }
 }
 
@@ -356,6 +378,26 @@ OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, in
 // arguments the builtin's checks are deferred to instantiation time, where the host pass of hipcc silently drops the kernel.
 OMG_DEV void dma16(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, voff, soff, 0, 0);
+}
+
+// The residual sub-tile of one wave (128 rows x 128 columns, 32 KB) into LDS by LDS-DMA: 32 instructions of 4 rows x 256 bytes, every one
+// of them whole 256-byte row segments (the register-direct loads of the epilogue touch 32 rows x 32 bytes per instruction: 64 cache-line
+// look-ups each; a K = 1280 projection with a residual ran 20 % below the same GEMM without one).  Image: row r of row block i at
+// i * 8192 + r * 256, its 16-byte piece c at position c ^ (r & 15) — the permutation is applied on the source side (the DMA destination is
+// lane-linear), and a ds_read_b128 of 16 lanes then covers all 64 banks.  Rows / columns outside the matrix read zeros (never stored).
+OMG_DEV void res_stage_dma(const GemmP& p, char* lds, int lane, int wm0, int wn0, int m_end) {
+  const __amdgpu_buffer_rsrc_t rsR = epi_rsrc(p.residual, ((long)(p.M - 1) * p.ldr + p.N) * 2);
+  const int rq = lane >> 4, pos = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int rr = u * 4 + rq;
+      const int gm = wm0 + i * 32 + rr;
+      const int col = wn0 + ((pos ^ (rr & 15)) << 3);
+      const int off = (gm < m_end && col < p.N) ? (gm * (int)p.ldr + col) * 2 : EPI_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsR, (lds_ptr_t)(lds + i * 8192 + u * 1024), 16, off, 0, 0, 0);
+    }
 }
 
 // 4 bytes per lane (256 contiguous bytes of LDS per instruction): per-row scale dwords of the MX-fp8 convolution

@@ -52,7 +52,7 @@ OMG_DEV f32x16 mfma_mx8(i32x8 a, i32x8 b, f32x16 c, int sa, int sb, int ks) {
 // scales are stored per pixel, SA[C/128][B*H*W] dwords (omg_groupnorm_mx8 writes them): every wave fetches the dwords of 64 of
 // the tile's rows with ONE 4-byte-per-lane LDS-DMA per stage at the tap-shifted pixel (out of range: byte 0 = 2^-127, times
 // zeros).  Weights [Cout][9 C] and their scales are those of the Linear path (omg_quant_mx8 of the packed conv weight).
-template <typename T, int D1, bool CONV = false, bool XE = true>
+template <typename T, int D1, bool CONV = false, bool XE = true, int EF = 0>
 __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
   constexpr int MT = 4, NT = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
 #undef MX_PREP
   // Transposed streaming epilogue (gemm_epilogue.h, XE): the 8 KB per wave it needs are taken from the stage buffer the LAST
   // stage does not use — released for every wave by that stage's barrier, never read or filled again.
-  epilogue_direct<T, MT, NT, XE>(p, acc, lane, m0 + wm * 128, n0 + wn * 128, m_end, gb_epi, smem + (nk & 1) * MX_STAGE + w * 8192);
+  epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane, m0 + wm * 128, n0 + wn * 128, m_end, gb_epi, smem + (nk & 1) * MX_STAGE + w * 8192);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,16 +340,17 @@ int launch_mx8(GemmP p, hipStream_t s, int mrows) {
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
   p.dbg = g_mx_dbg;
-#define MX_LAUNCH(D1_, XE_)                                                                                \
+#define MX_LAUNCH(D1_, XE_, EF_)                                                                           \
   do {                                                                                                     \
     static bool attr = false;                                                                              \
-    if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel<T, D1_, CONV, XE_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
-    OMG_LAUNCH((gemm_mx8_kernel<T, D1_, CONV, XE_>), dim3(grid), dim3(256), lds, s, p);                    \
+    if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel<T, D1_, CONV, XE_, EF_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
+    OMG_LAUNCH((gemm_mx8_kernel<T, D1_, CONV, XE_, EF_>), dim3(grid), dim3(256), lds, s, p);               \
   } while (0)
-  if (g_mx_dbg & 64) MX_LAUNCH(12, false);
-  else if (g_mx_d1 >= 16) MX_LAUNCH(16, true);
-  else if (g_mx_d1 >= 12) MX_LAUNCH(12, true);
-  else MX_LAUNCH(8, true);
+  if (g_mx_dbg & 64) MX_LAUNCH(12, false, 0);
+  else if (g_mx_d1 >= 16) MX_LAUNCH(16, true, 0);
+  else if (g_mx_d1 >= 12) MX_LAUNCH(12, true, 0);      // (one kernel per epilogue form, as gemm.hip does for v7, was measured 15-30 % SLOWER
+                                                       // here: the specialised builds split the K loop into several basic blocks)
+  else MX_LAUNCH(8, true, 0);
 #undef MX_LAUNCH
   return omg_check_launch("gemm_mx8");
 }

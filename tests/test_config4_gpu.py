@@ -153,8 +153,9 @@ def test_config4_composition_matches_the_oracle_loop(dev):
                                "relative to the rms of the oracle's final latents", "fp16_max": e16, "mx8_max": e8, "mx8_rms": r8}, f)
     except OSError:
         pass
-    # bound = measured (profiles/r03_config4_loop_parity.json) + margin; the 16-bit bound is 2e-2
-    assert max(r8) < 0.25 and max(e8) < 1.2, (max(r8), max(e8))
+    # measured on MI355X (profiles/r03_config4_loop_parity.json): fp16 max 8.8e-3; MX-fp8 rms 0.13, max 0.57 of the latent rms at step 8
+    # (the error grows with the step count here because 8 steps are all inside the growth phase, cf. the 50-step curve) — bound = + ~50 %
+    assert max(r8) < 0.2 and max(e8) < 0.9, (max(r8), max(e8))
 
 
 def _fresh(octl, args):
@@ -239,5 +240,6 @@ def test_fifty_step_error_growth_mx8(dev):
     except OSError:
         pass
     assert max(curves["fp16"]["max_abs_over_rms"]) < 2e-2
-    # measured (profiles/r03_error_growth_mx8.json) + margin
-    assert max(curves["mx8"]["rms_err_over_rms"]) < 0.35 and max(curves["mx8"]["max_abs_over_rms"]) < 1.8
+    # measured on MI355X (profiles/r03_error_growth_mx8.json): fp16 5.3e-3 max / 1.5e-3 rms; MX-fp8 0.40 max / 0.104 rms of the latent rms,
+    # both flat from step ~10 on (the fusion steps add nothing) — the loop-level tolerance of the fp8 mode, stated in bench.py's dtype string
+    assert max(curves["mx8"]["rms_err_over_rms"]) < 0.16 and max(curves["mx8"]["max_abs_over_rms"]) < 0.65

@@ -15,10 +15,11 @@ dev = torch.device("cuda:0")
 x = torch.randn(M, K, device=dev, dtype=torch.float16)
 w = torch.randn(N, K, device=dev, dtype=torch.float16)
 out = torch.empty(M, N, device=dev, dtype=torch.float16)
+RES = torch.randn(M, N, device=dev, dtype=torch.float16) if len(sys.argv) > 6 and sys.argv[6] == "res" else None
 var = int(sys.argv[5]) if len(sys.argv) > 5 else 15
 lib.omg_debug_set_gemm_variant(var | ((16 | extra) << 8))
 for _ in range(3):
-    ops.gemm(x, w, out=out)
+    ops.gemm(x, w, out=out, residual=RES)
 torch.cuda.synchronize()
 nb = min(8192, ((M + 255) // 256) * ((N + 255) // 256))
 buf = (ctypes.c_longlong * (6 * nb))()
@@ -43,10 +44,10 @@ k0 = sorted(cus)[0]
 print("one slot:", [(e[0], e[1], e[2], e[3]) for e in cus[k0][:6]])
 lib.omg_debug_set_gemm_variant(var | (extra << 8))
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-ops.gemm(x, w, out=out)
+ops.gemm(x, w, out=out, residual=RES)
 s.record()
 for _ in range(10):
-    ops.gemm(x, w, out=out)
+    ops.gemm(x, w, out=out, residual=RES)
 e.record()
 torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 10
