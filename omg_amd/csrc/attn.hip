@@ -20,6 +20,7 @@
 // chunk ^= (row >> 1) & 7: any 16 rows distinct mod 16 then cover the 16 slots of the 256-byte bank row exactly once
 // (conflict-free ds_read_b128; the first version XOR-ed row & 7 and read V in 8-byte pieces: 2-way / 4-way conflicts).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -239,6 +240,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel2(AttnP p) {
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* attn_gbl_ptr_t;
 
+//   * the kernel is bound by VALU issue, not by the matrix pipe (PMC, profiles/r02_pmc_attention_v3.json: 1664 VALU-issue cycles
+//     against 1024 MFMA cycles per wave and tile, and only ~5 VALU issues fit under one MFMA), so VALU instructions are what is
+//     removed: (1) the softmax denominator comes out of the matrix pipe — a register fragment of ones as one more "V^T row" gives
+//     sum_k P[q][k] in an extra accumulator (8 MFMAs per tile instead of 64 additions per lane; the sum is over the same 16-bit P
+//     that multiplies V); (2) no score is masked: keys past Nkv are staged as copies of the last key (their score cannot raise the
+//     maximum), the V^T columns past Nkv are zero (ops.transpose_v), and in the ragged last tile — peeled out of the loop at compile
+//     time, the compiler had speculated its 70 index additions and compares into every tile — the ones fragment is 0 at those keys.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
@@ -302,8 +310,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
   }
 
   const int ntiles = (p.Nkv + KVB - 1) / KVB;
+  const int nfull = p.Nkv / KVB;             // tiles with 64 real keys
   dma_tile(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
+  auto tile_body = [&](const int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = t & 1;
     const int kv0 = t * KVB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile t has landed
@@ -328,15 +338,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
     V8 pf[QW][2][2];
 #pragma unroll
     for (int qb = 0; qb < QW; ++qb) {
-      if (kv0 + KVB > p.Nkv) {      // key tail (last tile only)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kv0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key >= p.Nkv) s[qb][i][r] = -1e30f;
-          }
-      }
       float mt = s[qb][0][0];
 #pragma unroll
       for (int r = 1; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][0][r]), r + 1 < 16 ? s[qb][0][r + 1] : s[qb][0][r]);
@@ -355,22 +356,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[qb][r] = -m_ref[qb];
       }
-      float psum = 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const float e0 = __builtin_amdgcn_exp2f(s[qb][i][r]);
           const float e1 = __builtin_amdgcn_exp2f(s[qb][i][r + 1]);
-          psum += e0 + e1;
           const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
           pf[qb][i][r >> 3][r & 7] = pk[0];
           pf[qb][i][r >> 3][(r & 7) + 1] = pk[1];
         }
-      l_run[qb] += psum;
     }
 
-    // ---- O^T += V^T · P^T: each V^T fragment feeds two MFMAs
+    // ---- O^T += V^T · P^T: each V^T fragment feeds two MFMAs; the tile's row sums of P accumulate in `den`, which lives only here
+    // (the score registers are dead by now) — every one of its rows is the sum for the lane's query
+    f32x16 den[QW];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) den[qb][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -383,12 +387,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
 #pragma unroll
           for (int qb = 0; qb < QW; ++qb) o[qb][dt] = Vec<T>::mfma32(vf, pf[qb][i][k2], o[qb][dt]);
         }
+        V8 ones;                             // element e of this lane half pairs with key i*32 + k2*16 + (e >> 2)*8 + 4*hi + (e & 3)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (T)((!TAIL || kv0 + i * 32 + k2 * 16 + (e >> 2) * 8 + 4 * hi + (e & 3) < p.Nkv) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) den[qb] = Vec<T>::mfma32(ones, pf[qb][i][k2], den[qb]);
       }
-  }
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) l_run[qb] += den[qb][0];
+  };
+  for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+  if (nfull < ntiles) tile_body(nfull, std::true_type{});
 
 #pragma unroll
   for (int qb = 0; qb < QW; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float l_tot = l_run[qb];
     const float inv = p.out_scale / l_tot;
     if (qrow[qb] < p.Nq) {
       char* op = p.O + ((long)b * p.o_bs + (long)qrow[qb] * p.ldo + h * 64) * 2;

@@ -20,6 +20,8 @@ def timeit(fn, iters=10, warm=2):
 
 dev, dt = torch.device("cuda:0"), torch.float16
 lib = L.lib()
+VARS = (3,)
+print("# variants", VARS, "(3 = 64 rows per wave + LDS-DMA, 4 = 3 with the denominator on the matrix pipe, 5 = ping-pong wave groups, 6 = 5 + 4)")
 print("# (B, heads, Nq, Nkv): TF/s of v1 (running max) | v2 (reference max) | v3 (64 rows per wave, LDS-DMA); max |v3 - v1|")
 for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20, 1024, 77), (64, 10, 4096, 77), (32, 10, 4096, 4096), (64, 20, 1024, 16)]:
     C = heads * 64
@@ -30,10 +32,10 @@ for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20,
     out = torch.empty(B, Nq, C, device=dev, dtype=dt)
     fl = 4.0 * B * heads * Nq * Nkv * 64
     res, outs = [], []
-    for var in (1, 2, 3):
+    for var in VARS:
         lib.omg_debug_set_attn_variant(var)
         ms = timeit(lambda: ops.attention(q, k, vt, heads, 0.125, out=out))
         res.append(fl / ms / 1e9)
         outs.append(out.clone())
     lib.omg_debug_set_attn_variant(0)
-    print(f"({B},{heads},{Nq},{Nkv}): {res[0]:7.0f} | {res[1]:7.0f} | {res[2]:7.0f}   max |d| {(outs[0].float() - outs[2].float()).abs().max().item():.2e}")
+    print(f"({B},{heads},{Nq},{Nkv}): " + " | ".join(f"{r:7.0f}" for r in res) + f"   max |last - first| {(outs[0].float() - outs[-1].float()).abs().max().item():.2e}")
