@@ -198,7 +198,8 @@ typedef struct {
   int32_t B, heads, Nq, Nkv;  /* head_dim is 64                                       */
   const void* Q; int64_t ldq; int64_t q_bstride;   /* row stride / batch stride (elements) */
   const void* K; int64_t ldk; int64_t k_bstride;
-  const void* Vt;             /* [B, heads, 64, Nkv_pad] from omg_transpose_v (its key order) */
+  const void* Vt;             /* [B, heads, 64, Nkv_pad] from omg_transpose_v (its key order); columns >= Nkv MUST be zero (it writes
+                                 them so): the self-attention kernel masks no score, the padded keys cancel against those zeros */
   int32_t Nkv_pad;            /* % 64 == 0                                            */
   const int32_t* qk_src;      /* device [B]: batch index supplying Q,K; NULL = identity */
   float scale;
