@@ -131,4 +131,4 @@ def test_sdxl_unet_is_batch_invariant_at_full_size(dev):
     except OSError:
         pass
     # 70 transformer blocks and 17 resnet blocks of fp16 storage: measured + margin (profiles/r03_fullsize_forward_vs_oracle.json)
-    assert e_max < 6e-2 and e_rms < 1.5e-2, (e_max, e_rms)
+    assert e_max < 2e-2 and e_rms < 5e-3, (e_max, e_rms)

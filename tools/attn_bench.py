@@ -1,4 +1,4 @@
-"""Flash-attention kernel variants on the benchmark's shapes (GPU box).  python tools/attn_bench.py"""
+"""Flash-attention kernel variants on the benchmark's shapes (GPU box).  python tools/attn_bench.py [v v ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,9 +20,9 @@ def timeit(fn, iters=10, warm=2):
 
 dev, dt = torch.device("cuda:0"), torch.float16
 lib = L.lib()
-VARS = (3,)
-print("# variants", VARS, "(3 = 64 rows per wave + LDS-DMA, 4 = 3 with the denominator on the matrix pipe, 5 = ping-pong wave groups, 6 = 5 + 4)")
-print("# (B, heads, Nq, Nkv): TF/s of v1 (running max) | v2 (reference max) | v3 (64 rows per wave, LDS-DMA); max |v3 - v1|")
+VARS = tuple(int(a) for a in sys.argv[1:]) or (0,)
+print("# variants", VARS, "(0 = the heuristic: v3 above 128 keys, v2 below; 2 = v2; 3 = v3) — OMG_HIP_LIB=<other build> runs the same table on another library for A/B")
+print("# (B, heads, Nq, Nkv): TF/s per variant; max |last - first variant|")
 for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20, 1024, 77), (64, 10, 4096, 77), (32, 10, 4096, 4096), (64, 20, 1024, 16)]:
     C = heads * 64
     q = torch.randn(B, Nq, C, device=dev, dtype=dt)
