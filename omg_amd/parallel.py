@@ -66,3 +66,71 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Finer-grain option of SURVEY §8(e) / north_star "independent per-concept UNet passes ... shard across the GPUs":
+# within ONE lock-step batch, a denoising step is a set of independent forward UNITS — per request the main block
+# [unc0, unc1, cond0, cond1] (4 rows; cond1 borrows cond0's Q,K at every layer, so the block stays whole) and, in fused steps,
+# one [unc, cond] pair per masked concept (2 rows).  Ranks replicate the latents and the scheduler state; each step every rank
+# runs only its units through the UNet, ONE all_gather exchanges the fp32 noise predictions (<= 8 x 256 KiB per request: latency
+# bound), and every rank then executes the same fusion + CFG + scheduler kernel on the same inputs — the latents stay bitwise
+# replicated without a broadcast.  This is a LATENCY mode (critical path of a fused step: 4 of 4 + 2K rows); for throughput the
+# data-parallel split over images above has no per-step communication at all and is what bench.py measures.
+def assign_units(n_requests: int, n_concepts: int, fused: bool, world: int):
+    """Deterministic greedy balance of the step's units over ``world`` ranks.  Returns ``per_rank``: for every rank a pair
+    (main request indices, [(request, concept position)]).  Largest units first, to the least loaded rank, ties to the lowest rank —
+    every rank computes the same table."""
+    units = [(4, j, -1) for j in range(n_requests)]
+    if fused:
+        units += [(2, j, c) for j in range(n_requests) for c in range(n_concepts)]
+    load = [0] * world
+    per_rank = [([], []) for _ in range(world)]
+    for rows, j, c in sorted(units, key=lambda u: (-u[0], u[1], u[2])):
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += rows
+        (per_rank[r][0] if c < 0 else per_rank[r][1]).append(j if c < 0 else (j, c))
+    return per_rank
+
+
+def unit_rows(per_rank, n_requests: int, n_concepts: int):
+    """Row bookkeeping of :func:`assign_units` in the pipeline's batch layout (main rows ``4 j + r``; concept rows
+    ``4 n + 2 K j + 2 c + r``).  For every rank: ``src`` = rows of the MAIN block its local batch is filled from (a concept pair is
+    the request's edited conditional input ``4 j + 3`` twice, lora_pipeline.py:583-585) and ``dst`` = rows of the full prediction
+    buffer its outputs belong to; local order = main units first, then concept pairs."""
+    nm = 4 * n_requests
+    out = []
+    for mains, concs in per_rank:
+        src = [4 * j + r for j in mains for r in range(4)] + [4 * j + 3 for j, _ in concs for _ in range(2)]
+        dst = [4 * j + r for j in mains for r in range(4)] + [nm + 2 * n_concepts * j + 2 * c + r for j, c in concs for r in range(2)]
+        out.append((src, dst))
+    return out
+
+
+class ConceptShard:
+    """Handle passed to ``LoraMultiConceptPipeline.generate_many(concept_shard=...)``: this process' rank in the group that splits
+    one lock-step batch, and the exchange of the per-step predictions."""
+
+    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+        on = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.rank = (dist.get_rank(group) if on else 0) if rank is None else rank
+        self.world = (dist.get_world_size(group) if on else 1) if world is None else world
+
+    def exchange(self, local: torch.Tensor, counts: Sequence[int], dsts: Sequence[torch.Tensor], full: torch.Tensor) -> None:
+        """``local``: (max(counts), ...) buffer whose first ``counts[rank]`` rows are this rank's predictions; after the call row
+        ``dsts[r][i]`` of ``full`` holds row i of rank r, for every rank — one all_gather of equally sized buffers."""
+        if self.world == 1:
+            full.index_copy_(0, dsts[0], local[: counts[0]])
+            return
+        if local.is_cuda and dist.get_backend(self.group) == "gloo":       # gloo has no all_gather on device tensors (tests: two ranks on one GPU)
+            host = local.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(parts, host, group=self.group)
+            parts = [t.to(local.device) for t in parts]
+        else:                                                                # RCCL over xGMI
+            parts = [torch.empty_like(local) for _ in range(self.world)]
+            dist.all_gather(parts, local.contiguous(), group=self.group)
+        for r in range(self.world):
+            if counts[r]:
+                full.index_copy_(0, dsts[r], parts[r][: counts[r]])

@@ -257,7 +257,7 @@ class LoraMultiConceptPipeline:
                       trajectory: Optional[list] = None, fusion_start: int = FUSION_START, lora_mode: str = "merged",
                       controlnet=None, controlnet_image: Optional[torch.Tensor] = None, controlnet_conditioning_scale: float = 1.0,
                       identitynet=None, identitynet_conditioning_scale: float = 1.0, dedup: bool = False,
-                      concept_lora: bool = True) -> torch.Tensor:
+                      concept_lora: bool = True, concept_shard=None) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -274,7 +274,12 @@ class LoraMultiConceptPipeline:
         (stage 1: for the whole call).  With the batch-invariant kernels of this package those steps run ``[unc, cond]`` once per
         request and write the result to both samples — bitwise the same latents as the full batch (tests/test_pipeline_gpu.py),
         16 x 2 of the 336 sample-forwards of a 50-step stage-2 call fewer.  Used only where it is provably exact: equal prompt /
-        pooled / negative embeddings of the two samples, no controller or a pure-replacement one."""
+        pooled / negative embeddings of the two samples, no controller or a pure-replacement one.
+
+        ``concept_shard`` (:class:`omg_amd.parallel.ConceptShard`, every rank of its group calls with the SAME requests): the step's
+        independent forward units — the main block of a request, each concept pair — are split over the ranks, one all_gather
+        per step exchanges the noise predictions and every rank applies the same fusion + CFG + scheduler kernel, so all ranks
+        return the same latents, bitwise equal to the unsharded call (SURVEY §8(e) finer-grain option; latency, not throughput)."""
         dev, dt = self.unet.device, self.unet.dtype
         n = len(requests)
         height = height or self.unet.config.sample_size * self.vae_scale_factor
@@ -323,7 +328,8 @@ class LoraMultiConceptPipeline:
                     ip_l.append(torch.cat([rie[c] for c in act], dim=0).to(device=dev, dtype=dt))
                     kps_l.append(r["kps_image"].to(device=dev, dtype=torch.float32))
         Ka = len(active)
-        twin = bool(dedup) and (controller is None or getattr(controller, "is_pure_replacement", False))
+        shard = concept_shard if (concept_shard is not None and concept_shard.world > 1) else None
+        twin = bool(dedup) and shard is None and (controller is None or getattr(controller, "is_pure_replacement", False))
         if twin:      # both samples of every request must be the same computation: [neg0, neg1, pos0, pos1] with equal halves
             for e, tx in zip(ehs_l, text_l):
                 twin = twin and torch.equal(e[0], e[1]) and torch.equal(e[2], e[3]) and torch.equal(tx[0], tx[1]) and torch.equal(tx[2], tx[3])
@@ -380,12 +386,15 @@ class LoraMultiConceptPipeline:
         if use_idn and not batched:
             raise L.OmgHipError("identitynet runs in the batched mode only: merged / no LoRA, and concept_models built on the pipeline's own "
                                 "UNet (omg_amd.compat's from_pretrained shares it between the main and the concept pipe)")
+        if shard is not None and ((fuse_possible and not batched) or use_idn or (controller is not None and not getattr(controller, "is_pure_replacement", False))):
+            raise L.OmgHipError("concept_shard needs the batched step (merged / no LoRA on one shared UNet), a pure-replacement controller and no IdentityNet")
         mshape = tuple(masks_l[0][active[0]].shape) if active else (0, 0)
         D = emb_main.shape[-1]
         # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
         key = (n, S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
                str(dt), batched, bool(styleL), tuple(lora_list), mshape, tuple(ehs.shape), id(controller), id(controlnet), id(identitynet),
-               float(controlnet_conditioning_scale), float(identitynet_conditioning_scale), twin)
+               float(controlnet_conditioning_scale), float(identitynet_conditioning_scale), twin,
+               (shard.rank, shard.world) if shard is not None else None)
         eng = self._engines.pop(key, None)
         if eng is not None:
             self._engines[key] = eng                       # most recently used last
@@ -425,6 +434,27 @@ class LoraMultiConceptPipeline:
                 eng.kps_all = torch.empty((n, 3, height, width), dtype=torch.float32, device=dev)
                 eng.idn_emb = torch.empty((S, ncn, D), dtype=dt, device=dev)
                 eng.idn_emb_cur = torch.empty((ncn, D), dtype=dt, device=dev)
+            if shard is not None:      # per regime (plain / fused): this rank's units, its compact local batch and every rank's row map
+                from . import parallel as _par
+                eng.sh = {}
+                for fz in ((False, True) if fuse_possible else (False,)):
+                    per_rank = _par.assign_units(n, Ka, fz, shard.world)
+                    rows = _par.unit_rows(per_rank, n, Ka)
+                    mains, concs = per_rank[shard.rank]
+                    src, dst = rows[shard.rank]
+                    sh = SimpleNamespace(mains=mains, concs=concs, rows=len(src), n_main=4 * len(mains), counts=[len(r[1]) for r in rows])
+                    sh.src = torch.tensor(src, dtype=torch.long, device=dev)
+                    sh.dsts = [torch.tensor(r[1], dtype=torch.long, device=dev) for r in rows]
+                    sh.x = torch.empty((sh.rows, Cl, Hl, Wl), dtype=dt, device=dev)
+                    sh.y = torch.zeros((max(sh.counts), Cl, Hl, Wl), dtype=torch.float32, device=dev)
+                    sh.ehs = torch.empty((sh.rows,) + tuple(ehs.shape[1:]), dtype=dt, device=dev)
+                    sh.emb = torch.empty((S, sh.rows, D), dtype=dt, device=dev)
+                    sh.emb_cur = torch.empty((sh.rows, D), dtype=dt, device=dev)
+                    if use_cn and sh.n_main:
+                        sh.cn_emb = torch.empty((S, sh.n_main, D), dtype=dt, device=dev)
+                        sh.cn_emb_cur = torch.empty((sh.n_main, D), dtype=dt, device=dev)
+                        sh.cn_image = torch.empty((len(mains) if controlnet_image.shape[0] != 1 else 1, 3, height, width), dtype=torch.float32, device=dev)
+                    eng.sh[fz] = sh
             while len(self._engines) >= self.max_engines:      # least recently used first; its captured graphs go with it
                 old_key = next(iter(self._engines))
                 self._engines.pop(old_key)
@@ -489,7 +519,25 @@ class LoraMultiConceptPipeline:
                 eng.cn_emb2.copy_(eng.cn_emb.index_select(1, rows2))
             if main_slot >= 0:
                 state_twin = concept_models.lora_state([main_slot + 1] * (2 * n), merged=True) if merged else concept_models.lora_state([main_slot] * (2 * n), merged=False)
-        if use_graph:
+        if shard is not None:
+            for fz, sh in eng.sh.items():
+                if not sh.rows:
+                    continue
+                src_e, src_m = (eng.ehs_all, eng.emb_all) if fz else (eng.ehs, eng.emb_main)
+                sh.ehs.copy_(src_e.index_select(0, sh.dsts[shard.rank]))
+                sh.emb.copy_(src_m.index_select(1, sh.dsts[shard.rank]))
+                sh.state = None
+                if bank is not None and (main_slot >= 0 or sh.concs):
+                    sh.state = concept_models.lora_state([main_slot + 1] * sh.n_main + [jj + 1 for _, jj in sh.concs for _ in range(2)], merged=True)
+                if use_cn and sh.n_main:
+                    sh.cn_emb.copy_(eng.cn_emb.index_select(1, sh.dsts[shard.rank][: sh.n_main]))
+                    sh.cn_image.copy_(eng.cn_image if eng.cn_image.shape[0] == 1 else eng.cn_image[sh.mains])
+                if use_graph:
+                    self.unet.refresh_cross_kv(sh.ehs, sh.state)
+                    if use_cn and sh.n_main:
+                        controlnet.refresh_cross_kv(sh.ehs[: sh.n_main])
+                        controlnet.cond_features(sh.cn_image)
+        if use_graph and shard is None:
             # cached cross-attention K/V (and ControlNet conditioning features) must be refreshed eagerly:
             # replayed graphs read the stored tensors
             if twin:
@@ -578,6 +626,10 @@ class LoraMultiConceptPipeline:
                     fill_region_inputs()
                     ops.gather_step(eng.emb_conc, step_idx, eng.emb_cur_conc)
                     concept_models.unet_batched(xin[nm:], None, eng.c_ehs, slots, emb=eng.emb_cur_conc, out=nout[nm:])
+            finish(fused)
+
+        def finish(fused: bool):
+            """Region fusion + CFG + scheduler update + next model input of every request (one launch each)."""
             for j in range(n):
                 regs: List[Optional[torch.Tensor]] = [None] * K
                 if fused:
@@ -588,11 +640,41 @@ class LoraMultiConceptPipeline:
                                   fuse=fused, region_preds=regs, masks=eng.masks[j] if fused else [None] * K,
                                   model_input_next=xin[4 * j: 4 * j + 4], advance=(j == n - 1))
 
+        def shard_forward(fused: bool, _tw: bool = False):
+            """This rank's units of the step: main blocks first, then concept pairs, as one compact batch."""
+            sh = eng.sh[fused]
+            kw = dict(main_kw)
+            kw["omg_images"] = len(sh.mains)
+            sh.x.copy_(xin[:nm].index_select(0, sh.src))
+            if use_cn and sh.n_main:
+                ops.gather_step(sh.cn_emb, step_idx, sh.cn_emb_cur)
+                d_, m_ = controlnet(sh.x[: sh.n_main], None, encoder_hidden_states=sh.ehs[: sh.n_main], controlnet_cond=sh.cn_image,
+                                    conditioning_scale=controlnet_conditioning_scale, emb=sh.cn_emb_cur)
+                kw["omg_residuals"] = [(0, sh.n_main, d_, m_)]
+            ops.gather_step(sh.emb, step_idx, sh.emb_cur)
+            self.unet.set_lora_state(sh.state)
+            try:
+                self.unet(sh.x, None, encoder_hidden_states=sh.ehs, cross_attention_kwargs=kw, emb=sh.emb_cur, out=sh.y[: sh.rows])
+            finally:
+                self.unet.set_lora_state(None)
+
         def run_step(i: int):
             fused = fuse_possible and i > fusion_start
             tw = twin and not fused          # the samples part ways at the first fused step (stage 1: never)
+            if shard is not None:
+                sh = eng.sh[fused]
+                if sh.rows:
+                    run_forward(shard_forward, fused, False, ("shard", fused))
+                elif controller is not None:
+                    controller.cur_step += 1          # no unit of this step is ours: only the host-side step counter moves
+                shard.exchange(sh.y, sh.counts, sh.dsts, nout)
+                finish(fused)
+                return
+            run_forward(step_body, fused, tw, (fused,))
+
+        def run_forward(body, fused: bool, tw: bool, tag: tuple):
             if not use_graph:
-                step_body(fused, tw)
+                body(fused, tw)
                 return
             if eng.epoch != pointer_epoch():          # a weight image or cached K/V the graphs point at was freed or re-allocated
                 eng.graphs.clear()
@@ -600,7 +682,7 @@ class LoraMultiConceptPipeline:
                 eng.pool = None                       # the pool dies with its last graph: a later capture must open a new one
                 eng.epoch = pointer_epoch()
             win = controller._self_window() if controller is not None and hasattr(controller, "_self_window") else None
-            regime = (fused, win, tw)
+            regime = tag + (win, tw)
             g = eng.graphs.get(regime)
             if g is not None:
                 g.replay()
@@ -608,13 +690,13 @@ class LoraMultiConceptPipeline:
                     controller.cur_step += 1          # the replayed graph does not run the host-side counters
                 return
             if regime not in eng.warmed:              # first step of a regime runs eagerly (lazy inits, caches)
-                step_body(fused, tw)
+                body(fused, tw)
                 eng.warmed.add(regime)
                 return
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
             with torch.cuda.graph(g, pool=eng.pool):
-                step_body(fused, tw)                  # records the step; host counters tick as in eager mode
+                body(fused, tw)                       # records the step; host counters tick as in eager mode
             if eng.pool is None:
                 eng.pool = g.pool()
             eng.graphs[regime] = g

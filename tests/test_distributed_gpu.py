@@ -20,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_requests(indices):
+def _run_requests(indices, concept_shard=None, use_graph=False, controlnet=False):
     """Final latents of the requests `indices` (seeded by their GLOBAL index), batched in lock-step as bench.py does."""
     import contextlib, io
     from omg_amd import controller as pc
@@ -46,8 +46,17 @@ def _run_requests(indices):
         reqs.append(r)
     if not reqs:
         return torch.zeros((0, 2, 4, cfg.sample_size, cfg.sample_size))
+    extra = {}
+    if controlnet:
+        from omg_amd.controlnet import ControlNetModel
+        from oracle import controlnet as ocn, unet as ou          # seeded ControlNet weights in the shared key layout
+        cn = ControlNetModel(cfg, dtype=torch.float16, device=dev)
+        cn.load_state_dict({k: v.to(torch.float16) for k, v in ocn.init_state_dict(ou.UNetConfig.tiny(), seed=3).items()})
+        extra = dict(controlnet=cn, controlnet_conditioning_scale=0.8,
+                     controlnet_image=torch.rand(1, 3, HW, HW, generator=torch.Generator().manual_seed(9)))
     lat = pipe.generate_many(reqs, height=HW, width=HW, num_inference_steps=20, guidance_scale=7.5, cross_attention_kwargs={"scale": 0.8},
-                             controller=ctl, concept_models=concept, stage=2, lora_list=["concept0", "concept1"], styleL=False)
+                             controller=ctl, concept_models=concept, stage=2, lora_list=["concept0", "concept1"], styleL=False,
+                             concept_shard=concept_shard, use_graph=use_graph, **extra)
     return lat.cpu()
 
 
@@ -81,6 +90,38 @@ def test_pipeline_per_rank_then_gather_equals_single_process(dev):
         assert res[r].shape == single.shape
         assert torch.equal(res[r], single), f"rank {r}: gathered latents differ from the single-process run"
     assert not torch.equal(single[0], single[1])
+
+
+def _shard_worker(rank, world, port, n_images, use_graph, controlnet, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    from omg_amd import parallel
+    parallel.init_distributed(backend="gloo")
+    lat = _run_requests(list(range(n_images)), concept_shard=parallel.ConceptShard(), use_graph=use_graph, controlnet=controlnet)
+    parallel.barrier()
+    q.put((rank, lat))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_images,use_graph,controlnet", [(2, 1, False, False), (3, 1, True, False), (2, 2, True, True)])
+def test_concept_sharded_step_equals_the_unsharded_call(dev, world, n_images, use_graph, controlnet):
+    """north_star's "independent per-concept UNet passes ... shard across the GPUs" (finer-grain option): the ranks of a
+    ConceptShard split the forward units of every step (main block / concept pairs), exchange the noise predictions with one
+    all_gather per step and apply the same fusion + CFG + scheduler kernel — every rank ends with the latents of the unsharded call,
+    bit for bit (eager and with the local forward replayed from a hipGraph; with ControlNet on the main block)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, n_images, use_graph, controlnet, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    single = _run_requests(list(range(n_images)), controlnet=controlnet)
+    for r in range(world):
+        assert torch.equal(res[r], single), f"rank {r}: sharded latents differ from the unsharded call"
 
 
 def test_rccl_world_size_one_bench_smoke(dev):
