@@ -97,7 +97,9 @@ def _shard_worker(rank, world, port, n_images, use_graph, controlnet, q):
     sys.path.insert(0, ROOT)
     from omg_amd import parallel
     parallel.init_distributed(backend="gloo")
-    lat = _run_requests(list(range(n_images)), concept_shard=parallel.ConceptShard(), use_graph=use_graph, controlnet=controlnet)
+    shard = parallel.ConceptShard()
+    assert (shard.rank, shard.world) == (rank, world)
+    lat = _run_requests(list(range(n_images)), concept_shard=shard, use_graph=use_graph, controlnet=controlnet)
     parallel.barrier()
     q.put((rank, lat))
     torch.distributed.destroy_process_group()
