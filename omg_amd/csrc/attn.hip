@@ -229,6 +229,196 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel2(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// v6 (Nkv <= 128: cross-attention over the 77 text tokens / 93 with image-prompt tokens / 16 IP tokens): v2's arithmetic, bit for
+// bit, restructured for a launch that is bound by memory traffic and latency, not by the matrix pipe (two key tiles per query row).
+//   * K and V^T of a (sample, head) are staged ONCE per workgroup and stay in LDS for a strip of `q_chunk` query rows: v2 staged
+//     them per 128 rows — as many bytes from L2 as Q and O together — and paid their latency plus two block barriers per block;
+//   * after that single barrier the four waves run independently over the strip's 128-row steps; the next step's Q rows are
+//     requested before the current step computes;
+//   * O leaves as whole 128-byte row segments: the normalised tile goes through 4 KB of wave-private LDS (16-byte chunk ^ (row & 7))
+//     and is stored as 16 bytes per lane, 8 rows per instruction — v2 wrote 8 bytes per lane, 16 instructions per tile.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel6(AttnP p, int q_chunk) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 4 * 4096];   // K[2], Vt[2], O staging per wave
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bq = p.qk_src ? p.qk_src[b] : b;
+  const int ntiles = (p.Nkv + KVB - 1) / KVB;       // 1 or 2
+
+  {  // ---- K / V^T of the (sample, head): every tile, once
+    const int srow = tid >> 3, schunk = tid & 7;
+    const char* kbase = p.K + ((long)bq * p.k_bs + h * 64) * 2;
+    const char* vbase = p.Vt + ((long)(b * p.heads + h) * 64) * (long)p.Nkv_pad * 2;
+    for (int t = 0; t < ntiles; ++t) {
+      const int kv0 = t * KVB;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int row = ps * 32 + srow;
+        const int key = kv0 + row;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        const u32x4 hk = (key < p.Nkv) ? *(const u32x4*)(kbase + ((long)key * p.ldk + schunk * 8) * 2) : z;
+        const u32x4 hv = *(const u32x4*)(vbase + ((long)row * p.Nkv_pad + kv0 + schunk * 8) * 2);
+        const int off = row * 128 + ((schunk ^ ((row >> 1) & 7)) << 4);
+        *(u32x4*)(smem + t * TILE + off) = hk;
+        *(u32x4*)(smem + (2 + t) * TILE + off) = hv;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int q_begin = blockIdx.x * q_chunk;
+  const int q_end = q_begin + q_chunk < p.Nq ? q_begin + q_chunk : p.Nq;
+  char* ost = smem + 4 * TILE + w * 4096;
+  auto load_q = [&](int q0, V8* raw) {
+    int q = q0 + l31;
+    if (q > p.Nq - 1) q = p.Nq - 1;
+    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) raw[ks] = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
+  };
+  V8 raw[4];
+  int q0 = q_begin + w * 32;
+  if (q0 < q_end) load_q(q0, raw);
+  for (; q0 < q_end; q0 += QB) {
+    V8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ks][e] = (T)((float)raw[ks][e] * p.scale_log2e);
+    if (q0 + QB < q_end) load_q(q0 + QB, raw);       // in flight under this step's MFMAs
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_ref = 0.f, l_run = 0.f;
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+
+    for (int t = 0; t < ntiles; ++t) {
+      const int kv0 = t * KVB;
+      const char* kt = smem + t * TILE;
+      const char* vt = smem + (2 + t) * TILE;
+      // ---- S' = K · Q'^T - m_ref
+      f32x16 s[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + l31;
+        s[i] = Vec<T>::mfma32(*(const V8*)(kt + row * 128 + ((hi ^ ((row >> 1) & 7)) << 4)), qf[0], negm);
+      }
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) {
+        const int kc = ks * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = i * 32 + l31;
+          V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+          s[i] = Vec<T>::mfma32(kf, qf[ks], s[i]);
+        }
+      }
+      if (kv0 + KVB > p.Nkv) {      // key tail (last tile only)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= p.Nkv) s[i][r] = -1e30f;
+          }
+      }
+      // ---- tile maximum relative to the reference (pairs of fmaxf fuse into v_max3_f32)
+      float mt = s[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[0][r]), r + 1 < 16 ? s[0][r + 1] : s[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[1][r]), s[1][r + 1]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      if (t == 0 || __builtin_amdgcn_ballot_w64(mt > ATTN_THR) != 0) {
+        // raise (first tile: set) the reference: everything at the old reference is rescaled once, S' moves to the new one
+        const float d = t == 0 ? mt : fmaxf(mt, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m_ref += d;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o[i][r] *= alpha; s[i][r] -= d; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+      }
+      float psum = 0.f;
+      V8 pf[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(s[i][r]);
+          const float e1 = __builtin_amdgcn_exp2f(s[i][r + 1]);
+          psum += e0 + e1;
+          const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
+          pf[i][r >> 3][r & 7] = pk[0];
+          pf[i][r >> 3][(r & 7) + 1] = pk[1];
+        }
+      l_run += psum;
+
+      // ---- O^T += V^T · P^T
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int c0 = i * 4 + k2 * 2 + hi;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int row = dt * 32 + l31;
+            const V8 vf = *(const V8*)(vt + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
+            o[dt] = Vec<T>::mfma32(vf, pf[i][k2], o[dt]);
+          }
+        }
+    }
+
+    // ---- O: normalise, 16 bits, transpose through the wave's LDS strip, row-contiguous 16-byte stores
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = p.out_scale / l_tot;
+    const int q = q0 + l31;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[dt][g * 4 + e] * inv;
+        if (p.accumulate) {                          // the IP-Adapter branch adds into the text branch's output (same order as v2)
+          if (q < p.Nq) {
+            const V4 old = *(const V4*)(p.O + ((long)b * p.o_bs + (long)q * p.ldo + h * 64 + dt * 32 + 8 * g + 4 * hi) * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+          }
+        }
+        V4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = (T)v[e];
+        *(V4*)(ost + l31 * 128 + (((dt * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = out;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // one wave, in-order LDS: the tile is written before it is read back
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const u32x4 val = *(const u32x4*)(ost + row * 128 + ((ch ^ (row & 7)) << 4));
+      const int qr = q0 + row;
+      if (qr < p.Nq) *(u32x4*)(p.O + ((long)b * p.o_bs + (long)qr * p.ldo + h * 64 + ch * 8) * 2) = val;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and read back before the next step overwrites it
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // v3: v2's arithmetic with the LDS traffic per MFMA halved and no register staging.
 //   * a wave owns TWO 32-row query blocks (64 rows): every K / V^T fragment read from LDS feeds two MFMAs instead of one (v1 / v2
 //     read one ds_read_b128 per MFMA; with 8-12 waves per CU the LDS port was as busy as the matrix pipe), and the softmax VALU
@@ -555,11 +745,13 @@ AttnP make_params(const omg_attn_args* a) {
   return p;
 }
 
-int g_attn_variant = 0;      // 0 = heuristic (v3 / v2 by key count), 3 = v3 (64 query rows per wave, LDS-DMA staging), 2 = v2; tools / A-B tests only
+int g_attn_variant = 0;      // 0 = heuristic (v3 above 128 keys, v6 up to 128, v2 when O is not 16-byte aligned), 2 / 3 / 6 force one; tools / A-B tests only
 
 }  // namespace
 
-extern "C" void omg_debug_set_attn_variant(int v) { g_attn_variant = v; }
+static int g_attn_qchunk = 512;     // v6: query rows per workgroup strip (tools: bits 8.. of the variant word, in units of 128)
+
+extern "C" void omg_debug_set_attn_variant(int v) { g_attn_variant = v & 0xff; g_attn_qchunk = (v >> 8) ? (v >> 8) * 128 : 512; }
 
 extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_attn_fwd: null args");
@@ -575,6 +767,12 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
     dim3 grid3((a->Nq + 255) / 256, a->heads, a->B);
     if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel3<f16>, grid3, dim3(256), 0, s, p);
     else OMG_LAUNCH(attn_fwd_kernel3<bf16>, grid3, dim3(256), 0, s, p);
+  } else if ((g_attn_variant == 6 || g_attn_variant == 0) && a->Nkv <= 2 * KVB && a->ldo % 8 == 0 && a->o_bstride % 8 == 0 &&
+             ((uintptr_t)a->O & 15) == 0) {   // v6: K / V^T resident per (sample, head), strips of 512 query rows, 16-byte O stores
+    const int q_chunk = g_attn_qchunk;
+    dim3 grid6((a->Nq + q_chunk - 1) / q_chunk, a->heads, a->B);
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel6<f16>, grid6, dim3(256), 0, s, p, q_chunk);
+    else OMG_LAUNCH(attn_fwd_kernel6<bf16>, grid6, dim3(256), 0, s, p, q_chunk);
   } else {
     if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel2<f16>, grid, dim3(256), 0, s, p);
     else OMG_LAUNCH(attn_fwd_kernel2<bf16>, grid, dim3(256), 0, s, p);

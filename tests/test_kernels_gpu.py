@@ -197,6 +197,35 @@ def test_attention_probability_borrowing(dev, dtype, Nq, Nkv):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(3, 5, 1000, 77), (2, 2, 1024, 93), (2, 3, 130, 16), (1, 2, 4096, 128), (2, 1, 600, 64)])
+def test_kv_resident_cross_attention_is_bitwise_the_per_block_kernel(dev, dtype, B, heads, Nq, Nkv):
+    """v6 (K / V^T of a (sample, head) resident in LDS for a strip of query rows, O through an LDS transpose) runs v2's
+    arithmetic in v2's order: plain, with borrowed Q,K, and accumulating into an existing output — ragged strips, one and two
+    key tiles, a full second tile."""
+    from omg_amd import _lib as L
+    Cc = heads * 64
+    q = rnd(B, Nq, Cc, dtype=dtype, dev=dev, scale=1.5)
+    k = rnd(B, Nkv, Cc, dtype=dtype, dev=dev, scale=1.5, seed=1)
+    v = rnd(B, Nkv, Cc, dtype=dtype, dev=dev, seed=2)
+    vt = ops.transpose_v(v, heads)
+    src = torch.tensor([max(0, b - 1) for b in range(B)], dtype=torch.int32, device=dev)
+    res = {}
+    try:
+        for var in (2, 6):
+            L.lib().omg_debug_set_attn_variant(var)
+            a = ops.attention(q, k, vt, heads, 0.125)
+            b_ = ops.attention(q, k, vt, heads, 0.125, qk_src=src)
+            c = a.clone()
+            ops.attention(q, k, vt, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
+            res[var] = (a, b_, c)
+    finally:
+        L.lib().omg_debug_set_attn_variant(0)
+    for x, y in zip(res[2], res[6]):
+        assert torch.equal(x, y)
+    close(res[6][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_protocol_mode(dev, dtype):
     B, heads, Nq, Nkv = 2, 3, 130, 77
     Cc = heads * 64

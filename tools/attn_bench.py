@@ -5,7 +5,7 @@ import torch
 from omg_amd import ops, _lib as L
 
 
-def timeit(fn, iters=10, warm=2):
+def timeit(fn, iters=30, warm=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
