@@ -19,6 +19,13 @@
 // order [0-3, 8-11 | 4-7, 12-15] so that a lane's operand is one ds_read_b128.  Both LDS tiles use rows of 128 B with
 // chunk ^= (row >> 1) & 7: any 16 rows distinct mod 16 then cover the 16 slots of the 256-byte bank row exactly once
 // (conflict-free ds_read_b128; the first version XOR-ed row & 7 and read V in 8-byte pieces: 2-way / 4-way conflicts).
+//
+// Three kernels share this arithmetic (dispatch at the bottom of the file):
+//   attn_fwd_kernel3   Nkv > 128 (self-attention): 64 query rows per wave, K / V^T tiles by LDS-DMA, softmax denominator from an
+//                      MFMA against a ones fragment, no score masking (padded keys cancel against zero V^T columns);
+//   attn_fwd_kernel6   Nkv <= 128 (cross-attention over 77 / 93 / 16 tokens): K / V^T resident per (sample, head) over strips of
+//                      512 query rows, O through a wave-private LDS transpose; bitwise equal to kernel2;
+//   attn_fwd_kernel2   the per-128-row form of the latter: fallback when O is not 16-byte aligned, and the A/B baseline.
 #include "common.h"
 #include <type_traits>
 
