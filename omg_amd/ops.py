@@ -473,17 +473,14 @@ def attn_apply_probs(p: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tens
     return out
 
 
-_gn_ws = {}
-
-
 def _gn_workspace(device, B: int, groups: int, HW: int) -> torch.Tensor:
+    """Partial-sum scratch of one GroupNorm call.  Allocated PER CALL: a module-level buffer that grew on demand was, under
+    hipGraph capture, born in the capturing engine's private pool — a graph of ANOTHER engine captured later kept the pointer, and
+    when the first engine dropped its graphs (pointer epoch) the block was unmapped under the survivor's replay (memory access
+    fault in a stage 1 -> stage 2 sequence at full size, round 3).  Inside a capture torch gives every call its own slot of the
+    graph's pool; outside, the caching allocator makes this a free-list lookup."""
     n = int(L.lib().omg_groupnorm_ws_floats(B, groups, HW))
-    key = (device, torch.cuda.current_stream().cuda_stream)
-    ws = _gn_ws.get(key)
-    if ws is None or ws.numel() < n:
-        ws = torch.empty(max(n, 1 << 16), dtype=torch.float32, device=device)
-        _gn_ws[key] = ws
-    return ws
+    return torch.empty(max(n, 1), dtype=torch.float32, device=device)
 
 
 def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,

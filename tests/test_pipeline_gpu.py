@@ -358,6 +358,28 @@ def test_stale_graphs_are_dropped_when_the_bank_is_rebuilt(dev):
     assert torch.equal(ga2, eager_a), (ga2 - eager_a).abs().max()
     # the concept passes always run at the reference's hard-coded LoRA scale 0.8 (lora_pipeline.py:596): the caller's scale does not reach them
     assert torch.equal(run([m1, m2], False, scale=0.5), eager_a)
+    # two engines alive at once (the reference's own sequence: stage 1, then stage 2 with the masks), one of them re-capturing after
+    # the other's call rebuilt the bank: no captured graph may hold a pointer into ANOTHER engine's graph pool (round 3: the
+    # GroupNorm scratch buffer did, and the full-size stage 1 -> stage 2 sequence faulted when the first engine dropped its graphs)
+    def run_stage1(use_graph):
+        pe1, pp1 = embeds(cfg, 1, 3, dtype); ne1, np1 = embeds(cfg, 1, 53, dtype)
+        regions = []
+        for c in range(2):
+            re_, rp_ = embeds(cfg, 2, 13 + c, dtype)
+            regions.append((re_[0:1], re_[1:2], rp_[0:1], rp_[1:2]))
+        pctl.reset()
+        return pipe(output_type="latent", prompt_embeds=pe1.repeat(2, 1, 1), negative_prompt_embeds=ne1.repeat(2, 1, 1), pooled_prompt_embeds=pp1.repeat(2, 1),
+                    negative_pooled_prompt_embeds=np1.repeat(2, 1), height=H, width=W, num_inference_steps=S, guidance_scale=gs,
+                    latents=torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(5)), cross_attention_kwargs={"scale": 0.8},
+                    controller=pctl, concept_models=concept, stage=1, lora_list=["c0", "c1"], styleL=False,
+                    region_prompt_embeds=regions, use_graph=use_graph).images.cpu()
+    eager_1 = run_stage1(False)
+    for _ in range(2):
+        assert torch.equal(run_stage1(True), eager_1)
+        assert torch.equal(run([m1, None], True), eager_b)      # rebuilds the bank: the stage-1 engine's graphs go stale ...
+        assert torch.equal(run([m1, m2], True), eager_a)         # ... and this engine's, while the other two stay alive
+    from omg_amd import ops as _ops
+    assert not hasattr(_ops, "_gn_ws"), "no module-level device scratch: under capture it would live in one engine's graph pool"
     # ... but it is the scale of the main pass's style adapter: same engine key, the bank rebuilt with another style scale
     gs8 = run([m1, m2], True, scale=0.8, styleL=True)
     gs5 = run([m1, m2], True, scale=0.5, styleL=True)

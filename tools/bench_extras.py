@@ -93,7 +93,7 @@ if a.what in ("ips", "both"):
             print(json.dumps({"measurement": "images_per_step", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec, "sec_per_step": sec,
                               "workload": "BASELINE configs[1], stage-2 call + VAE decode of both images", "steps_timed": a.steps}), flush=True)
     else:
-        n = 8
+        n = int(a.ips.split(",")[-1])
         def both(i):
             rq = reqs_for(n, i)
             ctl.reset()
