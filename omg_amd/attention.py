@@ -212,8 +212,11 @@ class Attention(nn.Module):
         return k, vt
 
 
-def _ip_branch(attn: Attention, q: torch.Tensor, o: torch.Tensor, ip_ctx: torch.Tensor, row0: int) -> None:
-    """o[row0:] += ip_scale * softmax(q[row0:] K_ip^T) V_ip   (src/ip_adapter/attention_processor.py:391-409)."""
+def _ip_kv(attn: Attention, ip_ctx: torch.Tensor):
+    """K / V^T of the image-prompt tokens for this layer, cached per (pointer, version, shape) of ``ip_ctx``; a change of content
+    recomputes INTO the stored tensors, so the pointers a captured graph recorded stay valid.  Called by the forward and — before
+    step graphs are replayed on a new request — eagerly by ``UNet2DConditionModel.refresh_ip_kv`` (a replay runs no Python: without
+    that refresh the second request of a graph-mode InstantID session attended to the FIRST request's identity tokens)."""
     stamp = (ip_ctx.data_ptr(), ip_ctx._version, tuple(ip_ctx.shape))
     c = attn._ip_cache
     if c is None or c[0] != stamp:
@@ -225,6 +228,12 @@ def _ip_branch(attn: Attention, q: torch.Tensor, o: torch.Tensor, ip_ctx: torch.
         vt = ops.transpose_v(kv3[:, :, attn.inner_dim:], attn.heads, out=vt_out)
         c = (stamp, kv3[:, :, :attn.inner_dim], vt, kv, tuple(ip_ctx.shape), ip_ctx)
         attn._ip_cache = c
+    return c
+
+
+def _ip_branch(attn: Attention, q: torch.Tensor, o: torch.Tensor, ip_ctx: torch.Tensor, row0: int) -> None:
+    """o[row0:] += ip_scale * softmax(q[row0:] K_ip^T) V_ip   (src/ip_adapter/attention_processor.py:391-409)."""
+    c = _ip_kv(attn, ip_ctx)
     ops.attention(q[row0:], c[1], c[2], attn.heads, attn.scale, out=o[row0:], accumulate=True, out_scale=attn.ip_scale)
 
 

@@ -553,6 +553,7 @@ class LoraMultiConceptPipeline:
             if use_idn:
                 identitynet.refresh_cross_kv(eng.ip_all)
                 identitynet.cond_features(eng.kps_all)
+                self.unet.refresh_ip_kv(eng.ip_all)      # the UNet's own image-prompt K / V^T of the concept samples
 
         def region_rows(j):
             return nm + 2 * Ka * j

@@ -417,6 +417,13 @@ class UNet2DConditionModel(nn.Module):
         finally:
             self.set_lora_state(None)
 
+    def refresh_ip_kv(self, ip_ctx: torch.Tensor) -> None:
+        """Same for the image-prompt K / V^T of every attn2 that carries IP-Adapter weights (InstantID concept samples)."""
+        from .attention import _ip_kv
+        for _, m in self.attentions():
+            if m.is_cross and getattr(m, "ip_kv_weight", None) is not None:
+                _ip_kv(m, ip_ctx)
+
     # ------------------------------------------------------------------ forward
     def _boundary_weights(self):
         if not self._boundary:
