@@ -18,6 +18,7 @@ import torch
 
 from . import ops
 from .attention import Attention
+from .modules import bump_pointer_epoch
 
 
 def attn_processor_index(unet) -> Dict[str, int]:
@@ -53,6 +54,7 @@ class IPAdapter:
         m.ip_kv_weight = torch.cat([wk, wv], dim=0).to(device=dev, dtype=dt).contiguous()      # [2C, Cx]
         m.ip_scale, m.ip_tokens = self.scale, self.num_tokens
         m._ip_cache = None
+        bump_pointer_epoch()        # captured step graphs hold the old weight / cache pointers
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         if "ip_adapter" in sd:
@@ -84,10 +86,13 @@ class IPAdapter:
         return self
 
     def set_scale(self, scale: float) -> None:
+        if scale != self.scale:
+            bump_pointer_epoch()    # the scale is a launch argument of the captured attention kernels
         self.scale = scale
         for _, _, m in self.layers:
             m.ip_scale = scale
 
     def remove(self) -> None:
+        bump_pointer_epoch()
         for _, _, m in self.layers:
             m.ip_kv_weight = None

@@ -472,8 +472,11 @@ class LoraMultiConceptPipeline:
         lat.copy_(torch.cat(lats, dim=0))
         eng.ehs.copy_(ehs)
         eng.emb_main.copy_(emb_main)
-        if eng.coef is None:
-            eng.coef = self.scheduler.coef_table(dev)
+        coef_now = self.scheduler.coef_table(dev)          # per call: the key holds the scheduler's class and step count, not its
+        if eng.coef is None:                               # configuration — a re-configured scheduler must not meet a cached table
+            eng.coef = coef_now
+        else:
+            eng.coef.copy_(coef_now)                       # in place: captured graphs keep the pointer
         eng.step_idx.zero_()
         for j in range(n):
             for c in active:
