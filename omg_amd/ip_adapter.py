@@ -12,11 +12,10 @@ modules and the processors apply them to the row range named by ``omg_ip_rows``.
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 
-from . import ops
 from .attention import Attention
 from .modules import bump_pointer_epoch
 
