@@ -885,6 +885,10 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v7");
 }
 
+#ifdef OMG_EXP_KSCHED      // make EXP=1: the round-3 K-loop experiment (never run yet), variant 35
+#include "gemm_v10_exp.h"
+#endif
+
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -932,6 +936,15 @@ int launch(const GemmP& p, hipStream_t s) {
     // what the large-tile kernels do not handle (!v6ok) falls through to the 128x128 kernel below
     if (v == 24 && v6ok) return launch_v7<T, CONV, 0, 2, 5>(p, s, mrows);
     if (v == 15 && v6ok) return launch_v7<T, CONV>(p, s, mrows);
+#ifdef OMG_EXP_KSCHED
+    if (v == 35 && v6ok) {      // experiment: v7's tile and epilogues, reads two k-steps ahead (gemm_v10_exp.h)
+      const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;
+      if (p.act == OMG_ACT_GEGLU) return launch_v10<T, CONV, 3>(p, s, mrows);
+      if (gb_rows || p.act == OMG_ACT_SILU) return launch_v10<T, CONV, 4>(p, s, mrows);
+      if (p.residual != nullptr) return launch_v10<T, CONV, 2>(p, s, mrows);
+      return launch_v10<T, CONV, 1>(p, s, mrows);
+    }
+#endif
     if (v == 25 && v6ok) {      // one kernel per epilogue form (gemm_epilogue.h, EF)
       const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
       if (p.act == OMG_ACT_GEGLU) return launch_v7<T, CONV, 0, 4, 4, true, 3>(p, s, mrows);

@@ -312,6 +312,17 @@ def test_timestep_embedding_and_silu(dev, dtype):
 
 
 # ------------------------------------------------------------------ every tile variant gives the same bits
+def _experimental_variants():
+    """35 = gemm_kernel_v10 (csrc/gemm_v10_exp.h), present only in a library built with `make EXP=1`: found by looking for its
+    kernels in the code objects, so that an experimental build is validated by this test before anything is measured on it."""
+    try:
+        from tests import _codeobj
+        from omg_amd import _lib as L_
+        return (35,) if any("gemm_kernel_v10" in n for n in _codeobj.kernels(L_.LIB_PATH)) else ()
+    except Exception:
+        return ()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_variants_are_bitwise_identical(dev, dtype):
     """Batching requests changes the tile choice; results must not change with it (bias-first accumulation, same K order,
@@ -339,7 +350,7 @@ def test_gemm_variants_are_bitwise_identical(dev, dtype):
     try:
         lib.omg_debug_set_gemm_variant(1)
         base = run_all()
-        for v in (13, 14, 15, 24, 25):
+        for v in (13, 14, 15, 24, 25) + _experimental_variants():
             lib.omg_debug_set_gemm_variant(v)
             for k, (o, r) in enumerate(zip(run_all(), base)):
                 assert torch.equal(o, r), f"variant {v} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
