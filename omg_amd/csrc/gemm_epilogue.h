@@ -81,12 +81,15 @@ OMG_DEV __amdgpu_buffer_rsrc_t epi_rsrc(const char* base, long bytes) {
 }
 // 16 bytes at byte offset `off` (this lane's 8 consecutive columns) -> the 8 values in accumulator order (runs 0, 1)
 template <typename T>
-OMG_DEV void load_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, float (&f)[8]) {
-  const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0);
+OMG_DEV void decode_runs(const u32x4 raw, float (&f)[8]) {
   unsigned q[4] = {raw[0], raw[1], raw[2], raw[3]};
   swap_runs<T>(q);
   u32x4 sw = {q[0], q[1], q[2], q[3]};
   unpack8<T>(sw, f);
+}
+template <typename T>
+OMG_DEV void load_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, float (&f)[8]) {
+  decode_runs<T>(__builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0), f);
 }
 template <typename T>
 OMG_DEV void store_runs(__amdgpu_buffer_rsrc_t rs, int off, int soff, const float (&f)[8]) {
@@ -127,14 +130,26 @@ OMG_DEV bool acc_init_bias(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, int 
   const bool fold_gb = fold_group_bias(p);
   const __amdgpu_buffer_rsrc_t rsB = epi_rsrc(p.bias, (long)p.N * 2);
   const __amdgpu_buffer_rsrc_t rsG = epi_rsrc(fold_gb ? p.group_bias + (long)(m0 / p.rows_per_group) * p.ldgb * 2 : nullptr, (long)p.N * 2);
+  // All 2 * 2 * NT loads are issued before the first one is decoded.  Written load -> decode -> load -> decode, every load sat behind an
+  // `s_waitcnt vmcnt(0)` + the volatile lane swap of the previous one (round 3, found in the ISA): sixteen L2 round trips in series at the
+  // top of EVERY tile — and the first wait also covered the 16 LDS-DMA of stage 0 — i.e. most of the 3-4 us "prologue" the per-CU
+  // timeline showed.
+  u32x4 rb[NT][2], rg[NT][2];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       const int c = wn0 + j * 32 + pr * 16 + hi * 8;      // c >= N is beyond num_records: zeros
+      rb[j][pr] = __builtin_amdgcn_raw_buffer_load_b128(rsB, c * 2, 0, 0);
+      rg[j][pr] = __builtin_amdgcn_raw_buffer_load_b128(rsG, c * 2, 0, 0);
+    }
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
       float f[8], g[8];
-      load_runs<T>(rsB, c * 2, 0, f);
-      load_runs<T>(rsG, c * 2, 0, g);
+      decode_runs<T>(rb[j][pr], f);
+      decode_runs<T>(rg[j][pr], g);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
