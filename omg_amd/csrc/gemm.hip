@@ -12,7 +12,9 @@
 //                         the large-tile kernels do not take (the LoRA second K-segment, K % 64 != 0, operands >= 2 GiB).
 //   v6 (gemm_kernel_v6)   256x{256,128}x64 on eight waves, LDS-DMA issued between MFMA quartets through buffer descriptors; 256x128 in use.
 //   v7 (gemm_kernel_v7)   256x256 (and 128x320 for the convs of width 320 k) on FOUR waves, 128x128 per wave, K loop
-//                         software-pipelined inside the wave, one barrier per stage — the workhorse (>= 70 % of the time).
+//                         software-pipelined inside the wave, one barrier per stage; in use for the 128x320 conv tile.
+//   v11 (gemm_v11.h)      round 4: v7's 256x256 tile with a table-driven K loop on five rotating half-stage LDS buffers, LDS-DMA spread
+//                         over the whole stage — the workhorse (>= 70 % of the time).
 // (Round 3 removed v5 — the eight-wave predecessor of v6 — and v8, a persistent form of v7 that spilled: DESIGN.md §5.)
 // Common to all: v_mfma_f32_32x32x16, tiles staged global->LDS with LDS-DMA (1 KiB per wave instruction) into a
 // double-buffered, XOR-swizzled image — the DMA destination is lane-linear, so the swizzle is applied to the per-lane
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 
 bool g_use_glds = true;
 int g_dbg = 0;
-int g_variant = 0;   // 0 = heuristic; 1 = 128x128 v1; 13/14 = v6 256x256 / 256x128; 15 = v7 256x256; 24 = v7 128x320; 25 = v7 256x256 with the transposed streaming epilogue
+int g_variant = 0;   // 0 = heuristic; 1 = 128x128 v1; 13/14 = v6 256x256 / 256x128; 15 = v7 256x256; 24 = v7 128x320; 25 = v11 256x256 (ring K loop, transposed streaming epilogue)
 
 template <typename T, bool CONV, int MT>
 int launch_v6(GemmP p, hipStream_t s, int mrows) {
@@ -885,9 +887,7 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v7");
 }
 
-#ifdef OMG_EXP_KSCHED      // make EXP=1: the round-3 K-loop experiment (never run yet), variant 35
-#include "gemm_v10_exp.h"
-#endif
+#include "gemm_v11.h"      // the 256x256 four-wave tile with the table-driven K loop: schedule 5 = variant 25 (make EXP=1: 35 + SCH too)
 
 int num_cus() {
   static int n = 0;
@@ -937,22 +937,31 @@ int launch(const GemmP& p, hipStream_t s) {
     if (v == 24 && v6ok) return launch_v7<T, CONV, 0, 2, 5>(p, s, mrows);
     if (v == 15 && v6ok) return launch_v7<T, CONV>(p, s, mrows);
 #ifdef OMG_EXP_KSCHED
-    if (v == 35 && v6ok) {      // experiment: v7's tile and epilogues, reads two k-steps ahead (gemm_v10_exp.h)
-      const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;
-      if (p.act == OMG_ACT_GEGLU) return launch_v10<T, CONV, 3>(p, s, mrows);
-      if (gb_rows || p.act == OMG_ACT_SILU) return launch_v10<T, CONV, 4>(p, s, mrows);
-      if (p.residual != nullptr) return launch_v10<T, CONV, 2>(p, s, mrows);
-      return launch_v10<T, CONV, 1>(p, s, mrows);
+    if (v >= 35 && v <= 44 && v6ok) {      // make EXP=1: the other K-loop schedules of gemm_v11.h (tools/ksched_ab.py); 26 = round 3's v7 with the XE epilogue
+      switch (v - 35) {
+        case 1: return launch_v11_form<T, CONV, 1>(p, s, mrows);
+        case 5: return launch_v11_form<T, CONV, 5>(p, s, mrows);
+        case 8: return launch_v11_form<T, CONV, 8>(p, s, mrows);
+        case 9: return launch_v11_form<T, CONV, 9>(p, s, mrows);
+        default: if constexpr (!CONV) {
+          switch (v - 35) {
+            case 0: return launch_v11_form<T, CONV, 0>(p, s, mrows);
+            case 6: return launch_v11_form<T, CONV, 6>(p, s, mrows);
+            default: return launch_v11_form<T, CONV, 7>(p, s, mrows);
+          }
+        } else return launch_v11_form<T, CONV, 5>(p, s, mrows);
+      }
     }
-#endif
-    if (v == 25 && v6ok) {      // one kernel per epilogue form (gemm_epilogue.h, EF)
+    if (v == 26 && v6ok) {
       const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
       if (p.act == OMG_ACT_GEGLU) return launch_v7<T, CONV, 0, 4, 4, true, 3>(p, s, mrows);
       if (gb_rows || p.act == OMG_ACT_SILU) return launch_v7<T, CONV, 0, 4, 4, true, 4>(p, s, mrows);
-      if (p.residual != nullptr && !(g_dbg & 64)) return launch_v7<T, CONV, 0, 4, 4, true, 2>(p, s, mrows);
-      if (p.residual != nullptr) return launch_v7<T, CONV, 0, 4, 4, true, 0>(p, s, mrows);      // tools: register-direct residual (dbg 64)
+      if (p.residual != nullptr) return launch_v7<T, CONV, 0, 4, 4, true, 2>(p, s, mrows);
       return launch_v7<T, CONV, 0, 4, 4, true, 1>(p, s, mrows);
     }
+#endif
+    // 25: the 256x256 tile as the heuristic uses it — gemm_kernel_v11, schedule 5 (five rotating half-stage buffers), one kernel per epilogue form
+    if (v == 25 && v6ok) return launch_v11_form<T, CONV, 5>(p, s, mrows);
 #ifdef OMG_ABLATION_BUILDS   // make ABLATE=1: seven more instantiations of v7 for tools/gemm_ablate.py (3 minutes of compile time)
     if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
       if (v >= 17 && v <= 23 && v6ok) {

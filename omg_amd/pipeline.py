@@ -257,7 +257,9 @@ class LoraMultiConceptPipeline:
                       trajectory: Optional[list] = None, fusion_start: int = FUSION_START, lora_mode: str = "merged",
                       controlnet=None, controlnet_image: Optional[torch.Tensor] = None, controlnet_conditioning_scale: float = 1.0,
                       identitynet=None, identitynet_conditioning_scale: float = 1.0, dedup: bool = False,
-                      concept_lora: bool = True, concept_shard=None) -> torch.Tensor:
+                      concept_lora: bool = True, concept_shard=None,
+                      main_adapters: Optional[Sequence[Tuple[str, float]]] = None,
+                      concept_adapters: Optional[Sequence[Tuple[str, float]]] = None, concept_adapter_scale: float = 1.0) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -268,6 +270,13 @@ class LoraMultiConceptPipeline:
         ``identitynet`` (InstantID, instantid_pipeline.py:638-674): ControlNet on the CONCEPT pass fed with the face tokens and
         the request's ``kps_image`` (1,3,H,W); requests then also carry ``region_image_embeds`` = [(2,16,Cx) [zero-id, id]] * K and
         the UNet must have an :class:`omg_amd.ip_adapter.IPAdapter` installed.
+
+        ``main_adapters`` / ``concept_adapters`` [(name, weight)]: adapters of ``concept_models.bank`` that are simply ACTIVE on the main /
+        on every concept row — PEFT's state after ``load_lora_weights`` when nobody calls ``set_adapters`` (inference_instantid.py:220-222
+        loads a style LoRA into both pipes and the InstantID loop never selects adapters).  Main rows run them at the caller's
+        ``cross_attention_kwargs["scale"]`` (instantid_pipeline.py:596-616), concept rows at ``concept_adapter_scale`` (the concept UNet is
+        called with ``cross_attention_kwargs=None``, :665-674: scale 1.0).  ``styleL=True`` is ``main_adapters=[("style", 1.0)]`` plus the
+        LoRA flow's [concept, style] combination on the concept rows.
 
         ``dedup=True`` (OFF by default; SURVEY §7.4, "flag when used"): the reference duplicates the latents (:409) and is called
         with two equal prompts, so until the first fused step the two samples of a request are the same computation twice
@@ -351,23 +360,37 @@ class LoraMultiConceptPipeline:
         # (style slot) with the caller's cross_attention_kwargs (:546-566; PEFT's default scale is 1.0)
         main_scale = float((cross_attention_kwargs or {}).get("scale", 1.0))
         # InstantID's concepts are identities (IP-Adapter tokens + IdentityNet), not LoRA adapters: its `lora_list` only counts them
-        bank = concept_models.bank if (concept_models is not None and concept_lora) else None
+        main_adapters = [(str(a), float(w)) for a, w in (main_adapters or ())] or ([("style", 1.0)] if styleL else [])
+        concept_adapters = [(str(a), float(w)) for a, w in (concept_adapters or ())]
+        if concept_lora and concept_adapters:
+            raise ValueError("concept_adapters is the InstantID flow's 'whatever is active' rule; the LoRA flow selects adapters per concept (lora_list)")
+        bank = concept_models.bank if (concept_models is not None and (concept_lora or concept_adapters or main_adapters)) else None
         combos = []
-        if fuse_possible:
+        if fuse_possible and concept_lora:
             combos = [((lora_list[c], 0.7), ("style", 0.5)) if styleL else ((lora_list[c], 1.0),) for c in active]
         scales = [CONCEPT_LORA_SCALE] * len(combos)
+        if fuse_possible and concept_adapters:              # one combination for every concept row
+            combos, scales = [tuple(concept_adapters)], [float(concept_adapter_scale)]
         main_slot = -1
-        if styleL:
-            if bank is None or "style" not in bank.adapters:
-                raise ValueError("styleL=True needs concept_models with a LoraBank holding the adapter named 'style'")
+        if main_adapters:
+            if bank is None or any(a not in bank.adapters for a, _ in main_adapters):
+                raise ValueError(f"adapters {[a for a, _ in main_adapters]} on the main pass need concept_models with a LoraBank holding them"
+                                 + (" (styleL=True: the adapter named 'style')" if styleL else ""))
             main_slot = len(combos)
-            combos = combos + [(("style", 1.0),)]
+            combos = combos + [tuple(main_adapters)]
             scales.append(main_scale)
+        if concept_adapters and (bank is None or any(a not in bank.adapters for a, _ in concept_adapters)):
+            raise ValueError(f"concept_adapters {[a for a, _ in concept_adapters]} are not in concept_models' LoraBank")
         if bank is not None and combos:
             if [tuple(c) for c in combos] != list(bank.slots) or bank.scale != tuple(scales) or bank.mode != lora_mode:
                 bank.build(combos, scale=scales, mode=lora_mode)
         if fuse_possible:
-            slots = [s for _ in range(n) for s in range(Ka) for _ in range(2)] if bank is not None else [-1] * ncn
+            if bank is None or not (concept_lora or concept_adapters):
+                slots = [-1] * ncn
+            elif concept_adapters:
+                slots = [0] * ncn
+            else:
+                slots = [s for _ in range(n) for s in range(Ka) for _ in range(2)]
             c_ehs = torch.cat(cehs_l, dim=0).contiguous()                                           # (2Ka*n, 77, Cx)
             emb_conc = self._all_step_embeddings(ts, torch.cat(ctext_l, dim=0),
                                                  self._add_time_ids(original_size, crops_coords_top_left, target_size, ncn, dev),
@@ -392,7 +415,8 @@ class LoraMultiConceptPipeline:
         D = emb_main.shape[-1]
         # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
         key = (n, S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
-               str(dt), batched, bool(styleL), tuple(lora_list), mshape, tuple(ehs.shape), id(controller), id(controlnet), id(identitynet),
+               str(dt), batched, bool(styleL), tuple(main_adapters), tuple(concept_adapters), float(concept_adapter_scale), main_scale,
+               tuple(lora_list), mshape, tuple(ehs.shape), id(controller), id(controlnet), id(identitynet),
                float(controlnet_conditioning_scale), float(identitynet_conditioning_scale), twin,
                (shard.rank, shard.world) if shard is not None else None)
         eng = self._engines.pop(key, None)

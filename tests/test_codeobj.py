@@ -1,6 +1,7 @@
 """Static facts about the built kernels, read from the code objects inside libomg_hip.so (CPU, -m "not gpu"): what rocprofv3's
 Scratch_Size / VGPR columns would show, checked on every build instead of in a profile.  Skipped when the library has not been built."""
 import os
+import re
 
 import pytest
 
@@ -26,22 +27,20 @@ def test_every_kernel_is_wave64_without_dynamic_stack(ks):
         assert not k.get("uses_dynamic_stack", False), n
 
 
-def test_the_16_bit_gemm_instances_of_the_256_tile_keep_scratch_out_of_the_k_loop(ks):
-    """One XE instance per epilogue form: a spill reload waits on vmcnt, i.e. on every store and LDS-DMA in flight,
-    which cost the plain GEMM 20 % when the forms shared one kernel.  Bias-only (1), residual-through-LDS (2) and gb / SiLU (4) use
-    no scratch at all; GEGLU (3) parks ONE VGPR in the prologue and reloads it once at the top of the epilogue (checked in the ISA:
-    nothing between the first and the last MFMA); form 0 — every form behind run-time tests, tools only — is the spilling one."""
+def test_the_16_bit_gemm_instances_of_the_256_tile_use_no_scratch_at_all(ks):
+    """One instance per epilogue form: a spill reload waits on vmcnt, i.e. on every store and LDS-DMA in flight,
+    which cost the plain GEMM 20 % when the forms shared one kernel.  Round 4's gemm_kernel_v11 (table-driven K loop on five rotating
+    half-stage buffers, 128 fragment VGPRs + 256 accumulators) keeps every form — bias-only (1), residual-through-LDS (2), GEGLU (3),
+    gb / SiLU (4) — free of spills and scratch; the product build carries schedule 5 only."""
     seen = {}
-    for n, k in pick(ks, "gemm_kernel_v7", "Li0ELi4ELi4ELb1E").items():          # ABL = 0, MT = NT = 4, XE
-        form = int(n[n.index("Li4ELi4ELb1ELi") + len("Li4ELi4ELb1ELi")])
-        seen.setdefault(form, []).append((k["vgpr_spill_count"], k["private_segment_fixed_size"]))
+    for n, k in pick(ks, "gemm_kernel_v11").items():
+        m = re.search(r"Lb([01])ELi(\d)ELi(\d)EEEv", n)
+        conv, form, sch = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        seen.setdefault((form, sch), []).append(conv)
         assert k["agpr_count"] == 256 and k["max_flat_workgroup_size"] == 256, n        # 256 accumulators in AGPRs, one wave per SIMD
-        if form in (1, 2, 4):
-            assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (n, k["private_segment_fixed_size"])
-        elif form == 3:
-            assert k["vgpr_spill_count"] <= 1 and k["private_segment_fixed_size"] <= 8, (n, k["private_segment_fixed_size"])
-    assert sorted(seen) == [0, 1, 2, 3, 4] and all(len(v) == 4 for v in seen.values()), seen      # f16 / bf16 x Linear / conv
-    assert max(sz for _, sz in seen[0]) > 8, "form 0 is expected to be the spilling instance; if it no longer is, fold the forms back"
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0, (n, k["private_segment_fixed_size"])
+        assert k["group_segment_fixed_size"] == 0, n                                        # dynamic LDS only: 5 x 32 KB
+    assert all((f, 5) in seen and len(seen[(f, 5)]) == 4 for f in (1, 2, 3, 4)), seen      # f16 / bf16 x Linear / conv
     for n, k in pick(ks, "gemm_kernel_v7", "Li0ELi2ELi5E").items():                # the 128 x 320 conv tile
         assert k["private_segment_fixed_size"] == 0, n
 
@@ -58,7 +57,7 @@ def test_attention_kernels_fit_two_workgroups_per_cu_without_scratch(ks):
 
 def test_scratch_users_are_known_and_small(ks):
     """Whatever spills must be on this list with a bound — a new entry is a regression to look at, not to wave through."""
-    allowed = {"gemm_mx8_kernel": 128, "gemm_kernel_v7": 96}       # bytes per lane.  v7: form 0 (tools) and GEGLU's one register; MX-fp8: its XE epilogue (4-26 VGPRs, DESIGN §5)
+    allowed = {"gemm_mx8_kernel": 128, "gemm_kernel_v7": 96}       # bytes per lane.  v7: EXP builds only (round 3's XE forms: GEGLU's one register); MX-fp8: its XE epilogue (4-26 VGPRs, DESIGN §5)
     for n, k in ks.items():
         sz = k["private_segment_fixed_size"]
         if sz:
@@ -66,7 +65,7 @@ def test_scratch_users_are_known_and_small(ks):
             assert fam and sz <= allowed[fam[0]], (n, sz)
 
 
-@pytest.mark.parametrize("family", ["gemm_kernel_v7", "gemm_mx8_kernel", "attn_fwd_kernel3", "attn_fwd_kernel6"])
+@pytest.mark.parametrize("family", ["gemm_kernel_v11", "gemm_kernel_v7", "gemm_mx8_kernel", "attn_fwd_kernel3", "attn_fwd_kernel6"])
 def test_no_scratch_access_between_the_first_and_the_last_mfma(family):
     """Where the spilled registers of the table above are touched: never inside the MFMA region (K loop / key-tile loop).  A scratch
     reload there would wait on vmcnt and with it on the LDS-DMA of the next stage (any scratch use in a one-block-per-CU

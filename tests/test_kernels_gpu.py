@@ -313,12 +313,14 @@ def test_timestep_embedding_and_silu(dev, dtype):
 
 # ------------------------------------------------------------------ every tile variant gives the same bits
 def _experimental_variants():
-    """35 = gemm_kernel_v10 (csrc/gemm_v10_exp.h), present only in a library built with `make EXP=1`: found by looking for its
-    kernels in the code objects, so that an experimental build is validated by this test before anything is measured on it."""
+    """A library built with `make EXP=1` also holds the other K-loop schedules of gemm_kernel_v11 (35 + SCH; csrc/gemm_v11.h) and round
+    3's v7 with the XE epilogue (26): found by looking for a non-product schedule in the code objects, so that an experimental build is
+    validated by this test before anything is measured on it."""
     try:
         from tests import _codeobj
         from omg_amd import _lib as L_
-        return (35,) if any("gemm_kernel_v10" in n for n in _codeobj.kernels(L_.LIB_PATH)) else ()
+        exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in _codeobj.kernels(L_.LIB_PATH))
+        return (26, 35, 36, 40, 41, 42, 43, 44) if exp else ()
     except Exception:
         return ()
 

@@ -21,6 +21,25 @@ shapes = [(65536, 10240, 1280, "geglu"), (65536, 1280, 1280, ""), (65536, 1280, 
 if SEL == "n640":      # the 640-wide Linear layers: 256-wide tiles pad N to 768
     shapes = [(262144, 640, 640, "res"), (262144, 640, 640, ""), (262144, 640, 2560, "res"), (131072, 640, 640, "res"), (262144, 1920, 640, ""), (262144, 5120, 640, "geglu"),
               (131072, 640, 2560, "res"), (65536, 1280, 1280, "res"), (32768, 1280, 1280, "res")]
+if SEL == "conv":      # 3x3 convolutions of the UNet on the 256x256 tile: (B, H, W, Cin, Cout)
+    for B, H, W_, Ci, Co in [(64, 32, 32, 1280, 1280), (64, 64, 64, 640, 640), (64, 32, 32, 2560, 1280), (64, 64, 64, 1280, 640), (16, 128, 128, 640, 640)]:
+        x = torch.randn(B, H, W_, Ci, device=dev, dtype=torch.float16)
+        w = torch.randn(Co, 9 * Ci, device=dev, dtype=torch.float16) * (9 * Ci) ** -0.5
+        b = torch.randn(Co, device=dev, dtype=torch.float16)
+        gb = torch.randn(B, Co, device=dev, dtype=torch.float16)
+        f = lambda: ops.conv2d(x, w, 3, bias=b, group_bias=gb)
+        ts, outs = {v: [] for v in VARS}, {}
+        for r in range(R):
+            for v in VARS:
+                lib.omg_debug_set_gemm_variant(v)
+                ts[v].append(t(f))
+                if r == 0:
+                    outs[v] = f().clone()
+        lib.omg_debug_set_gemm_variant(0)
+        fl = 2 * B * H * W_ * Co * 9 * Ci / 1e9
+        med = lambda a: sorted(a)[len(a) // 2]
+        print(f"conv {B}x{H}x{W_} {Ci}->{Co} " + "  ".join(f"v{v}: med {fl/med(ts[v]):6.0f} best {fl/min(ts[v]):6.0f} eq={int(torch.equal(outs[v], outs[VARS[0]]))}" for v in VARS), flush=True)
+    sys.exit(0)
 for M, N, K, kind in shapes:
     x = torch.randn(M, K, device=dev, dtype=torch.float16)
     w = torch.randn(N, K, device=dev, dtype=torch.float16) * K ** -0.5
