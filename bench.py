@@ -153,7 +153,16 @@ def main():
     ap.add_argument("--fp8-linear-only", action="store_true", help="with --dtype fp8: keep every convolution in fp16 (round-2 first fp8 line)")
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for power / clock during the timed region")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
+    ap.add_argument("--shard", default="images", choices=["images", "concept"],
+                    help="N > 1 only.  images (default, throughput, weak scaling): every rank runs its own requests, one all_gather of the final latents. "
+                         "concept (LATENCY of one batch, strong scaling; north_star's 'independent per-concept UNet passes shard across the GPUs'): every "
+                         "rank is handed the SAME requests, a step's forward units (main block, one [unc, cond] pair per masked concept) are split over "
+                         "the ranks and one all_gather per step exchanges the noise predictions (omg_amd.parallel.ConceptShard)")
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE configs[3]'s own shape: batch 32 over 8 GPUs = 4 requests per GPU and step (--images-per-step 4); the default 8 is the throughput optimum")
     args = ap.parse_args()
+    if args.config3:
+        args.images_per_step = 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (one rank per GPU over RCCL), as the N > 1 contract describes
@@ -200,11 +209,14 @@ def main():
     masks = c2_masks(HW, HW, device=dev)
     n_steps = args.warmup + args.steps
     ips = args.images_per_step
+    by_concept = args.shard == "concept" and world > 1
+    cshard = parallel.ConceptShard() if by_concept else None
     inputs = []
     for i in range(n_steps):                                                                       # resident in HBM
         reqs = []
         for j in range(ips):
-            r = c2_inputs(unet, seed=(rank * 1000 + i) * 16 + j, height=HW, width=HW)
+            # images: every rank has its own requests; concept: all ranks share them (the batch is split inside the step)
+            r = c2_inputs(unet, seed=((0 if by_concept else rank) * 1000 + i) * 16 + j, height=HW, width=HW)
             r["region_masks"] = masks
             reqs.append(r)
         inputs.append(reqs)
@@ -214,16 +226,22 @@ def main():
         ctl.reset()                                                                   # inference_lora.py:274
         lat = pipe.generate_many(reqs, height=HW, width=HW, num_inference_steps=args.denoise_steps, guidance_scale=7.5,
                                  cross_attention_kwargs={"scale": 0.8}, controller=ctl, concept_models=concept, stage=2,
-                                 lora_list=["concept0", "concept1"], styleL=False, use_graph=not args.no_graph, dedup=dedup)
+                                 lora_list=["concept0", "concept1"], styleL=False, use_graph=not args.no_graph, dedup=dedup and not by_concept,
+                                 concept_shard=cshard)
         if vae is not None:                                                           # both images of every request, two at a time
-            for j in range(lat.shape[0]):
+            for j in (range(lat.shape[0]) if not by_concept else parallel.shard_indices(lat.shape[0], rank, world)):      # concept: the decodes are split too
                 img = vae.decode_latents(lat[j])
             assert img.shape[-1] == lat.shape[-1] * 2 ** (len(vae.config.block_out_channels) - 1)
         return lat
 
+    def gather(lat):
+        if by_concept:                     # every rank already holds every request's latents (replicated state): nothing to exchange
+            return lat[:, 1].contiguous()
+        return parallel.gather_latents(lat[:, 1].contiguous(), world * ips, rank, world)
+
     for i in range(args.warmup):
         lat = run_step(inputs[i])
-        parallel.gather_latents(lat[:, 1].contiguous(), world * ips, rank, world)
+        gather(lat)
     sampler = PowerSampler(local) if rank == 0 and not args.no_power else None
     parallel.barrier()
     torch.cuda.synchronize()
@@ -232,7 +250,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, n_steps):
         lat = run_step(inputs[i])
-        allimg = parallel.gather_latents(lat[:, 1].contiguous(), world * ips, rank, world)       # the deliverable is images[1]
+        allimg = gather(lat)                                                                     # the deliverable is images[1]
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
@@ -240,10 +258,13 @@ def main():
     if sampler is not None:
         sampler.__exit__()
     assert torch.isfinite(allimg).all()
-    value = world * ips * args.steps / el
+    job_images = ips if by_concept else world * ips          # concept: ONE batch is split over the ranks (strong scaling)
+    value = job_images * args.steps / el
 
     # second timed region: the same requests with the exactly redundant forwards executed once (same barrier / sync bracket)
     n_dd = min(args.steps, 2) if args.dedup_steps < 0 else min(args.dedup_steps, n_steps)
+    if by_concept:
+        n_dd = 0                                              # the twin regime and the unit split are alternatives
     dedup = None
     if n_dd > 0:
         lat_full = lat
@@ -269,22 +290,25 @@ def main():
     out = {"metric": "images/sec @ SDXL 1024^2 50-step, 2-concept mask fusion", "value": value, "unit": "images/sec",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * el / args.steps,
            "value_dedup": dedup["value"] if dedup else None, "dedup": dedup,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "higher_is_better": True, "scaling": "strong" if by_concept else "weak", "vs_baseline": None,
            "dtype": ("fp8 (OCP MX e4m3 operands, fp32 accumulate) on the transformer Linear layers" + ("" if args.fp8_linear_only else " and the resnet 3x3 convolutions with Cin % 128 == 0")
                      + "; fp16 elsewhere; measured loop tolerance vs the fp32 oracle (50-step stage-2 trajectory, random-weight SDXL topology at reduced width: "
                        "profiles/r03_error_growth_mx8.json): rms error 0.10, max 0.40 of the latent rms, flat after step 10 (fp16 path: 1.5e-3 / 5.3e-3)") if args.dtype == "fp8" else args.dtype,
            "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: SDXL-base 1024x1024, %d %s steps, 2 concepts + 2 rank-64 LoRAs, masked "
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),
-                      "global_batch": world * ips, "images_per_step_per_gpu": ips, "main_batch": 4 * ips, "concept_batch": 4 * ips, "accounting": "stage-2 only, as executed by the reference "
+                      "global_batch": job_images, "images_per_step_per_gpu": ips if not by_concept else ips / world, "main_batch": 4 * ips, "concept_batch": 4 * ips, "accounting": "stage-2 only, as executed by the reference "
                       "(200 main + 136 concept sample-forwards = 2.273 PFLOP/image; 2.255 PFLOP executed per forward pass count, the cross-attention K / V "
                       "projections of the constant text context being cached per call); no redundancy shortcuts",
                       "vae_decode": "skipped (--no-vae)" if args.no_vae else ("both 1024^2 images of every request decoded inside the timed region, "
                                      + ("bf16 storage / fp32 accumulate (--vae-16bit)" if args.vae_16bit else "as the reference's upcast decode: fp16 post_quant / conv_in / mid block, fp32 up blocks on the f32-input MFMA")
                                      + "; +10.5 TFLOP per request, not counted in the FLOP accounting"),
-                      "parallelism": f"dp{world}", "tiny_debug": bool(args.tiny),
+                      "parallelism": (f"concept-shard over {world} ranks: per step the main block and the concept pairs of the {ips} request(s) are split "
+                                      f"over the ranks, one all_gather of the noise predictions per step (latency mode)") if by_concept else f"dp{world}",
+                      "tiny_debug": bool(args.tiny),
                       "step_loop": "eager" if args.no_graph else "hipGraph replay (3 captured step regimes)", "lora": "merged weight slots, "
                       "main + concept samples of all requests batched per fused step (8 samples per request)"},
+           "latency_s_per_batch": (el / args.steps) if by_concept else None,
            "end_to_end_tflops_per_gpu": (N_MAIN + N_CONCEPT) * SAMPLE_FWD_TFLOP * value / world if not args.tiny else None,
            # the same with the cached cross-attention K / V projections (0.78 % of a forward) taken out: what the GPU executed
            "end_to_end_tflops_per_gpu_executed": (N_MAIN + N_CONCEPT) * (SAMPLE_FWD_TFLOP - CACHED_KV_TFLOP) * value / world if not args.tiny else None}
@@ -313,10 +337,11 @@ def main():
         g_ms, g_fl, g_n = comb(fam, "ms"), comb(fam, "flops"), comb(fam, "launches")
         a_ms, a_fl = comb("attn", "ms"), comb("attn", "flops")
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        # HBM-side bytes cannot be counted from inside this process: the committed rocprofv3 --pmc measurement of the
-        # dominant GEMM shape (profiles/r01_pmc_traffic.json, method and gfx950 correction recorded there) is reported
+        # HBM-side bytes cannot be counted from inside this process: the committed rocprofv3 --pmc measurement of the dominant GEMM
+        # shape by tools/pmc_traffic.py (method and gfx950 correction recorded in the file) is reported — the newest round's file
         traffic, traffic_note = None, "no PMC measurement committed"
-        tfile = "r03_pmc_traffic_fp8.json" if args.dtype == "fp8" else "r03_pmc_traffic_fp16.json"
+        tag = "fp8" if args.dtype == "fp8" else "fp16"
+        tfile = next((f for f in (f"r04_pmc_traffic_{tag}.json", f"r03_pmc_traffic_{tag}.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
         try:      # tools/pmc_traffic.py wrote it from rocprofv3 --pmc passes of the kernel this line's roofline names
             with open(os.path.join(ROOT, "profiles", tfile)) as f:
                 pm = json.load(f)
@@ -326,7 +351,8 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         kname = ("gemm_mx8_kernel (transformer Linear layers + resnet convolutions, MX-fp8 operands on v_mfma_scale_f32_32x32x64_f8f6f4, per-sample weight slots)"
-                 if args.dtype == "fp8" else "gemm_kernel_v7 / gemm_kernel_v6 / gemm_kernel (Linear + implicit-GEMM conv, per-sample weight slots)")
+                 if args.dtype == "fp8" else "gemm_kernel_v11 (256x256 tile, ring K loop) / gemm_kernel_v7 (128x320 conv tile) / gemm_kernel_v6 / gemm_kernel "
+                 "(Linear + implicit-GEMM conv, per-sample weight slots)")
         out["roofline"] = {"bound": "mfma", "kernel": kname,
                            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                            "traffic_note": traffic_note,

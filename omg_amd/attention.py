@@ -213,21 +213,32 @@ class Attention(nn.Module):
 
 
 def _ip_kv(attn: Attention, ip_ctx: torch.Tensor):
-    """K / V^T of the image-prompt tokens for this layer, cached per (pointer, version, shape) of ``ip_ctx``; a change of content
-    recomputes INTO the stored tensors, so the pointers a captured graph recorded stay valid.  Called by the forward and — before
-    step graphs are replayed on a new request — eagerly by ``UNet2DConditionModel.refresh_ip_kv`` (a replay runs no Python: without
-    that refresh the second request of a graph-mode InstantID session attended to the FIRST request's identity tokens)."""
-    stamp = (ip_ctx.data_ptr(), ip_ctx._version, tuple(ip_ctx.shape))
-    c = attn._ip_cache
+    """K / V^T of the image-prompt tokens for this layer, cached PER SHAPE of ``ip_ctx`` (as ``project_cross`` caches per context shape):
+    a hit on (pointer, version) returns the stored projections; a change of content for a shape seen before recomputes INTO the stored
+    tensors, so the pointers a captured graph recorded stay valid.  Called by the forward and — before step graphs are replayed on a
+    new request — eagerly by ``UNet2DConditionModel.refresh_ip_kv`` (a replay runs no Python: without that refresh the second request
+    of a graph-mode InstantID session attended to the FIRST request's identity tokens).  Round 4: the cache held ONE
+    entry, so two InstantID engines of different shapes alternating A, B, A re-allocated A's tensors on the third call while A's
+    graphs still read the freed ones; now each shape keeps its tensors, and evicting the oldest of more than four bumps the pointer
+    epoch (every captured graph is dropped and re-recorded)."""
+    shape = tuple(ip_ctx.shape)
+    stamp = (ip_ctx.data_ptr(), ip_ctx._version)
+    cache = attn._ip_cache
+    if cache is None:
+        cache = attn._ip_cache = {}
+    c = cache.get(shape)
     if c is None or c[0] != stamp:
-        Bc, Ni, Cx = ip_ctx.shape
-        kv_out = c[3] if (c is not None and tuple(c[4]) == tuple(ip_ctx.shape)) else None
-        vt_out = c[2] if kv_out is not None else None
+        Bc, Ni, Cx = shape
+        kv_out = c[3] if c is not None else None
+        vt_out = c[2] if c is not None else None
         kv = ops.gemm(ip_ctx.reshape(Bc * Ni, Cx), attn.ip_kv_weight, out=kv_out)
         kv3 = kv.view(Bc, Ni, 2 * attn.inner_dim)
         vt = ops.transpose_v(kv3[:, :, attn.inner_dim:], attn.heads, out=vt_out)
-        c = (stamp, kv3[:, :, :attn.inner_dim], vt, kv, tuple(ip_ctx.shape), ip_ctx)
-        attn._ip_cache = c
+        if c is None and len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+            bump_pointer_epoch()                      # a captured graph may still point at the evicted K / V^T
+        c = (stamp, kv3[:, :, :attn.inner_dim], vt, kv, shape, ip_ctx)
+        cache[shape] = c
     return c
 
 

@@ -131,6 +131,7 @@ class _Components:
 
 
 _CACHE: Dict[Tuple[str, str], _Components] = {}
+_PRECISION_VARIANTS = {None, "fp16", "bf16", "fp32"}         # the same weights stored at another precision
 
 
 def _components(path: str, dtype: torch.dtype, variant: Optional[str]) -> _Components:
@@ -140,6 +141,12 @@ def _components(path: str, dtype: torch.dtype, variant: Optional[str]) -> _Compo
     key = (os.path.realpath(path), str(dtype))
     if key not in _CACHE:
         _CACHE[key] = _Components(path, dtype, variant)
+    elif variant != _CACHE[key].variant and not {variant, _CACHE[key].variant} <= _PRECISION_VARIANTS:
+        # "ema" and the like are OTHER weights, not the same weights at another precision: say so instead of silently sharing
+        import warnings
+        warnings.warn(f"{path}: already loaded with variant={_CACHE[key].variant!r}; the request for variant={variant!r} shares those modules "
+                      "(omg_amd.compat keeps ONE set of modules per directory and dtype — call clear_component_cache() to load the other files)",
+                      stacklevel=3)
     return _CACHE[key]
 
 
@@ -219,6 +226,20 @@ class _PipeMixin:
         self._comp.bank.adapters[name] = ad
         self._comp.bank.version += 1
         self._comp.bank.slots = []                              # force a rebuild at the next call
+        loaded = self.__dict__.setdefault("_loaded_adapters", [])
+        if name not in loaded:
+            loaded.append(name)
+
+    def peft_active_adapters(self) -> List[Tuple[str, float]]:
+        """What PEFT has switched on in THIS pipe when the loop never calls ``set_adapters``: ``load_lora_weights`` leaves the first
+        adapter loaded into a pipe active at weight 1.0 (later ones are injected inactive); an explicit ``set_adapters`` replaces that.
+        The InstantID flow relies on it — inference_instantid.py:220-222 loads a style LoRA into both pipes and
+        instantid_pipeline.py never selects adapters — the LoRA flow does not (lora_pipeline.py:339-342, :588-591 select explicitly)."""
+        explicit = getattr(self, "_active", ())
+        if explicit:
+            return [(n, float(w)) for n, w in explicit]
+        loaded = self.__dict__.get("_loaded_adapters", [])
+        return [(loaded[0], 1.0)] if loaded else []
 
 
 class StableDiffusionXLPipeline(_PipeMixin, ConceptModels):
@@ -359,9 +380,12 @@ class InstantidMultiConceptPipeline(_PipeMixin, _InstantidPipe):
         extra = {}
         if prompt is not None:
             # all prompts are encoded at once by the MAIN pipe (instantid_pipeline.py:336-375), no LoRA involved
+            # ... but a LoRA that load_lora_weights left active on the main pipe (inference_instantid.py:220-222) acts on its text
+            # encoders too, at lora_scale = cross_attention_kwargs["scale"] (instantid_pipeline.py:330-360)
             te_scale = (cross_attention_kwargs or {}).get("scale", None)
             glob, regions = list(prompt[0]), list(prompt[1])
-            pe, ne, pp, npp = self.encode_prompt(glob + [r[0] for r in regions], list(negative_prompt) + [r[1] for r in regions], None, te_scale)
+            pe, ne, pp, npp = self.encode_prompt(glob + [r[0] for r in regions], list(negative_prompt) + [r[1] for r in regions],
+                                                 self.peft_active_adapters() or None, te_scale)
             extra = dict(prompt_embeds=pe[:2], negative_prompt_embeds=ne[:2], pooled_prompt_embeds=pp[:2], negative_pooled_prompt_embeds=npp[:2],
                          region_prompt_embeds=[(ne[2 + c: 3 + c], pe[2 + c: 3 + c], npp[2 + c: 3 + c], pp[2 + c: 3 + c]) for c in range(len(regions))])
             if stage == 2:
@@ -372,5 +396,142 @@ class InstantidMultiConceptPipeline(_PipeMixin, _InstantidPipe):
             image = _cond_image_tensor(image, h, w)
         if t2i_image is not None:
             t2i_image = _cond_image_tensor(t2i_image, h, w)
+        # PEFT's "whatever load_lora_weights left switched on": main rows at cross_attention_kwargs["scale"] (:596-616), concept rows at 1.0
+        # (the concept UNet is called with cross_attention_kwargs=None, :665-674)
+        c_act = concept_models.peft_active_adapters() if hasattr(concept_models, "peft_active_adapters") else []
         return _InstantidPipe.__call__(self, image=image, t2i_image=t2i_image, height=height, width=width, concept_models=concept_models,
-                                       stage=stage, output_type=output_type, return_dict=return_dict, **extra, **kw)
+                                       stage=stage, output_type=output_type, return_dict=return_dict, cross_attention_kwargs=cross_attention_kwargs,
+                                       main_adapters=self.peft_active_adapters() or None, concept_adapters=c_act or None, **extra, **kw)
+
+
+# ------------------------------------------------------------------------------------------------ alias modules
+InstantidSingleConceptPipeline = StableDiffusionXLInstantIDPipeline      # the name inference_instantid.py:35 imports
+
+
+class _Unavailable:
+    """Stand-in for a class the scripts import but this backend does not provide (imported-but-unused names such as
+    ``DPMSolverMultistepScheduler`` at inference_instantid.py:8, or third-party models outside the hot path): importing is fine,
+    using it says what is missing."""
+
+    def __init__(self, name: str):
+        self._name = name
+
+    def __call__(self, *a, **k):
+        raise L.OmgHipError(f"{self._name} is not provided by omg_amd.compat (it is outside the denoising hot path); install the real package")
+
+    def __getattr__(self, attr):
+        raise L.OmgHipError(f"{self._name}.{attr}: {self._name} is not provided by omg_amd.compat; install the real package")
+
+
+def _save_image(tensor, fp, nrow: int = 8, **kw) -> None:
+    """``torchvision.utils.save_image`` for the one way the scripts use it (a (3, H, W) or (1, 3, H, W) tensor in [0, 1] to a file)."""
+    from PIL import Image
+    t = torch.as_tensor(tensor).detach().float().cpu()
+    if t.dim() == 4:
+        t = torch.cat(list(t), dim=2)                            # a row of images
+    if t.dim() == 2:
+        t = t[None]
+    a = (t.clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).numpy()
+    Image.fromarray(a[:, :, 0] if a.shape[2] == 1 else a).save(fp)
+
+
+def install(stub_missing: bool = True) -> List[str]:
+    """Make the reference's scripts run on this backend with their ORIGINAL import block (B3): registers, in ``sys.modules``, the module
+    names ``inference_lora.py:29-32`` and ``inference_instantid.py:8-13, :34-37`` import, backed by this package —
+
+        src.pipelines.lora_pipeline          LoraMultiConceptPipeline, revise_regionally_controlnet_forward
+        src.pipelines.instantid_pipeline     InstantidMultiConceptPipeline, revise_regionally_controlnet_forward
+        src.pipelines.instantid_single_pieline   InstantidSingleConceptPipeline
+        src.prompt_attention.p2p_attention   AttentionReplace
+        diffusers                            ControlNetModel, StableDiffusionXLPipeline (+ DPMSolverMultistepScheduler, models.T2IAdapter:
+                                             imported by the InstantID script and never used — placeholders), utils.load_image
+
+    so ``import omg_amd.compat as c; c.install()`` in front of the script (or ``python -c "import omg_amd.compat as c; c.install();
+    import runpy; runpy.run_path('inference_lora.py', run_name='__main__')"``) is the whole edit.  Call it BEFORE the script's imports; it
+    overrides a real ``diffusers`` for the process (that is its purpose).  ``stub_missing``: third-party modules of the import block that
+    are outside the hot path and absent from the environment get stand-ins — ``torchvision.utils.save_image`` (a real implementation
+    on PIL), ``cv2`` / ``insightface.app.FaceAnalysis`` (importable; using them raises).  Returns the names it registered."""
+    import importlib
+    import importlib.util
+    import sys
+    import types
+    from .controller import AttentionReplace
+    from .pipeline import revise_regionally_controlnet_forward
+
+    done: List[str] = []
+
+    def package(name: str):
+        """a real (namespace) package of that name stays; otherwise an empty stand-in package"""
+        if name in sys.modules:
+            return sys.modules[name]
+        try:
+            if importlib.util.find_spec(name) is not None:
+                return importlib.import_module(name)
+        except (ImportError, ValueError):
+            pass
+        m = types.ModuleType(name)
+        m.__path__ = []                                         # a package: submodules are looked up in sys.modules first
+        m.__omg_amd_alias__ = True
+        sys.modules[name] = m
+        done.append(name)
+        return m
+
+    def module(name: str, **attrs):
+        parent = name.rpartition(".")[0]
+        if parent:
+            package(parent.partition(".")[0])
+            acc = ""
+            for part in parent.split("."):
+                acc = part if not acc else acc + "." + part
+                package(acc)
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__omg_amd_alias__ = True
+        sys.modules[name] = m
+        if parent and isinstance(sys.modules.get(parent), types.ModuleType):
+            try:
+                setattr(sys.modules[parent], name.rpartition(".")[2], m)
+            except Exception:
+                pass
+        done.append(name)
+        return m
+
+    module("src.pipelines.lora_pipeline", LoraMultiConceptPipeline=LoraMultiConceptPipeline,
+           revise_regionally_controlnet_forward=revise_regionally_controlnet_forward)
+    module("src.pipelines.instantid_pipeline", InstantidMultiConceptPipeline=InstantidMultiConceptPipeline,
+           revise_regionally_controlnet_forward=revise_regionally_controlnet_forward)
+    module("src.pipelines.instantid_single_pieline", InstantidSingleConceptPipeline=InstantidSingleConceptPipeline,
+           StableDiffusionXLInstantIDPipeline=StableDiffusionXLInstantIDPipeline)
+    module("src.prompt_attention.p2p_attention", AttentionReplace=AttentionReplace)
+    for n in ("diffusers", "diffusers.models", "diffusers.utils"):
+        sys.modules.pop(n, None)
+    dm = module("diffusers.models", ControlNetModel=ControlNetModel, T2IAdapter=_Unavailable("diffusers.models.T2IAdapter"))
+    du = module("diffusers.utils", load_image=load_image)
+    d = package("diffusers")
+    d.__dict__.update(ControlNetModel=ControlNetModel, StableDiffusionXLPipeline=StableDiffusionXLPipeline,
+                      DPMSolverMultistepScheduler=_Unavailable("diffusers.DPMSolverMultistepScheduler"),
+                      DDIMScheduler=DDIMScheduler, EulerDiscreteScheduler=EulerDiscreteScheduler, models=dm, utils=du)
+    if stub_missing:
+        def absent(name: str) -> bool:
+            if name in sys.modules:
+                return False
+            try:
+                return importlib.util.find_spec(name) is None
+            except (ImportError, ValueError):
+                return True
+        if absent("torchvision"):
+            module("torchvision.utils", save_image=_save_image)
+        if absent("cv2"):
+            cv2 = module("cv2")
+            cv2.__getattr__ = lambda a: _Unavailable("cv2").__getattr__(a)          # PEP 562: any use says what is missing
+        if absent("insightface"):
+            module("insightface.app", FaceAnalysis=_Unavailable("insightface.app.FaceAnalysis"))
+    return done
+
+
+def uninstall() -> None:
+    """Remove what :func:`install` registered (names already imported from the aliases stay bound where they were imported)."""
+    import sys
+    # vars(), not getattr: lazy modules (transformers) import on attribute access and would grow sys.modules under the iteration
+    for n in [n for n, m in list(sys.modules.items()) if m is not None and getattr(m, "__dict__", {}).get("__omg_amd_alias__", False)]:
+        del sys.modules[n]

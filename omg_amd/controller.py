@@ -88,6 +88,8 @@ def _alignment_matrix(src_spans: Sequence[np.ndarray], tgt_spans: Sequence[np.nd
         r = np.arange(run)
         m[i + r, j + r] = 1
         i, j = i + run, j + run
+        if i >= max_len or j >= max_len:                        # the replacement starts exactly where the window ends (prompts longer than
+            return m                                            # 77 tokens: the reference's `while i < max_len and j < max_len` stops here)
         if len(s) == len(t):
             m[s, t] = 1
         else:

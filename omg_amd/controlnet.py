@@ -24,7 +24,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from .attention import Attention
-from .modules import Conv2d
+from .modules import Conv2d, bump_pointer_epoch
 from .unet import (CrossAttnDownBlock2D, DownBlock2D, TimestepEmbedding, UNetConfig, UNetMidBlock2DCrossAttn, _Ctx)
 
 COND_CHANNELS = (16, 32, 96, 256)
@@ -136,16 +136,28 @@ class ControlNetModel(nn.Module):
     del _U
 
     def cond_features(self, controlnet_cond: torch.Tensor) -> torch.Tensor:
-        """Conditioning embedding, cached per conditioning tensor (it does not depend on the denoising step)."""
-        key = (controlnet_cond.data_ptr(), controlnet_cond._version, tuple(controlnet_cond.shape))
-        c = self._cond_cache
-        if c is None or c[0] != key:
+        """Conditioning embedding (it does not depend on the denoising step), cached PER SHAPE of the conditioning tensor: a change of
+        content for a shape seen before recomputes INTO the stored tensor, so the pointer a captured step graph recorded stays valid.
+        Round 4: the cache held one entry — two graph-mode engines of different batch alternating (A, B, A, B) re-allocated the
+        other's features while its graphs still read the freed tensor (found by tests/test_instantid_gpu.py's alternation test, the
+        ControlNet-side twin of ADVICE r3's image-prompt K/V finding).  More than four shapes: the oldest goes and the pointer epoch is
+        bumped (captured graphs are dropped and re-recorded)."""
+        shape = tuple(controlnet_cond.shape)
+        stamp = (controlnet_cond.data_ptr(), controlnet_cond._version)
+        cache = self._cond_cache
+        if cache is None:
+            cache = self._cond_cache = {}
+        c = cache.get(shape)
+        if c is None or c[0] != stamp:
             feat = self.controlnet_cond_embedding(controlnet_cond)
-            if c is not None and c[1].shape == feat.shape:
+            if c is not None:
                 c[1].copy_(feat)                # keep the pointer stable for captured step graphs
                 feat = c[1]
-            self._cond_cache = (key, feat, controlnet_cond)
-        return self._cond_cache[1]
+            elif len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+                bump_pointer_epoch()
+            cache[shape] = (stamp, feat, controlnet_cond)
+        return cache[shape][1]
 
     def refresh_cross_kv(self, ctx: torch.Tensor) -> None:
         for m in self.modules():

@@ -116,6 +116,44 @@ class ConceptModels:
                                  return_dict=return_dict, **kw)
 
 
+class StageCache:
+    """Exact redundancy BETWEEN the two calls of one image (OFF unless a cache object is passed; "flag when used").
+
+    The reference's flow is stage 1 -> segment -> stage 2 with the SAME seed, prompts and kwargs (inference_lora.py:262-297), and the
+    fusion branch only fires for ``i > 15`` (lora_pipeline.py:568): steps 0..15 of the stage-2 call repeat steps 0..15 of the stage-1
+    call operation for operation.  A call with ``stage_cache=cache`` that runs those steps stores, per request, the latents ENTERING
+    the first fused step under a key made of everything that determines them (initial latents, all main-pass embeddings, step count,
+    guidance, scheduler table, size, adapters, ControlNet + image, UNet identity and weight version); a later stage-2 call that finds
+    every request's key starts at step 16 from the stored latents — 16 x 4 sample-forwards per image fewer, bitwise the same result
+    with this package's batch-invariant deterministic kernels (tests/test_pipeline_gpu.py).  Nothing is assumed: a miss runs the full call."""
+
+    def __init__(self, max_entries: int = 64):
+        self.entries: Dict[str, torch.Tensor] = {}
+        self.max_entries = max_entries
+        self.hits = 0
+        self.misses = 0
+
+    @staticmethod
+    def digest(*parts) -> str:
+        import hashlib
+        h = hashlib.sha1()
+        for p in parts:
+            if torch.is_tensor(p):
+                h.update(str((tuple(p.shape), str(p.dtype))).encode())
+                h.update(p.detach().contiguous().cpu().view(torch.uint8).numpy().tobytes())
+            else:
+                h.update(repr(p).encode())
+        return h.hexdigest()
+
+    def put(self, key: str, latents: torch.Tensor) -> None:
+        if key not in self.entries and len(self.entries) >= self.max_entries:
+            self.entries.pop(next(iter(self.entries)))
+        self.entries[key] = latents.detach().clone()
+
+    def get(self, key: str) -> Optional[torch.Tensor]:
+        return self.entries.get(key)
+
+
 class StableDiffusionXLPipelineOutput(SimpleNamespace):
     pass
 
@@ -220,7 +258,8 @@ class LoraMultiConceptPipeline:
                                  controller=controller, concept_models=concept_models, stage=stage, lora_list=lora_list,
                                  styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
                                  lora_mode=lora_mode, controlnet=controlnet if image is not None else None, controlnet_image=image,
-                                 controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0), dedup=dedup)[0]
+                                 controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0), dedup=dedup,
+                                 stage_cache=kwargs.pop("stage_cache", None))[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         images = self._postprocess(lat, output_type)
@@ -259,7 +298,8 @@ class LoraMultiConceptPipeline:
                       identitynet=None, identitynet_conditioning_scale: float = 1.0, dedup: bool = False,
                       concept_lora: bool = True, concept_shard=None,
                       main_adapters: Optional[Sequence[Tuple[str, float]]] = None,
-                      concept_adapters: Optional[Sequence[Tuple[str, float]]] = None, concept_adapter_scale: float = 1.0) -> torch.Tensor:
+                      concept_adapters: Optional[Sequence[Tuple[str, float]]] = None, concept_adapter_scale: float = 1.0,
+                      stage_cache: Optional[StageCache] = None) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -278,12 +318,16 @@ class LoraMultiConceptPipeline:
         called with ``cross_attention_kwargs=None``, :665-674: scale 1.0).  ``styleL=True`` is ``main_adapters=[("style", 1.0)]`` plus the
         LoRA flow's [concept, style] combination on the concept rows.
 
+        ``stage_cache`` (:class:`StageCache`, OFF by default): the steps in front of the first fused step of a stage-2 call
+        repeat the stage-1 call of the same image; with a cache shared by the two calls the second one starts at step ``fusion_start + 1``.
+
         ``dedup=True`` (OFF by default; SURVEY §7.4, "flag when used"): the reference duplicates the latents (:409) and is called
         with two equal prompts, so until the first fused step the two samples of a request are the same computation twice
         (stage 1: for the whole call).  With the batch-invariant kernels of this package those steps run ``[unc, cond]`` once per
         request and write the result to both samples — bitwise the same latents as the full batch (tests/test_pipeline_gpu.py),
         16 x 2 of the 336 sample-forwards of a 50-step stage-2 call fewer.  Used only where it is provably exact: equal prompt /
-        pooled / negative embeddings of the two samples, no controller or a pure-replacement one.
+        pooled / negative embeddings of the two samples, no controller or a pure-replacement one, and a ControlNet conditioning image
+        that is shared (1 image) or per request (n images) — with one image per main row the call falls back to the full batch.
 
         ``concept_shard`` (:class:`omg_amd.parallel.ConceptShard`, every rank of its group calls with the SAME requests): the step's
         independent forward units — the main block of a request, each concept pair — are split over the ranks, one all_gather
@@ -339,9 +383,14 @@ class LoraMultiConceptPipeline:
         Ka = len(active)
         shard = concept_shard if (concept_shard is not None and concept_shard.world > 1) else None
         twin = bool(dedup) and shard is None and (controller is None or getattr(controller, "is_pure_replacement", False))
-        if twin:      # both samples of every request must be the same computation: [neg0, neg1, pos0, pos1] with equal halves
-            for e, tx in zip(ehs_l, text_l):
-                twin = twin and torch.equal(e[0], e[1]) and torch.equal(e[2], e[3]) and torch.equal(tx[0], tx[1]) and torch.equal(tx[2], tx[3])
+        if twin and controlnet is not None and controlnet_image is not None and controlnet_image.shape[0] not in (1, n):
+            twin = False      # one conditioning image per MAIN ROW (4n): the two samples of a request may differ, and the 2n-row twin batch
+                              # would not divide it — full batch instead
+        if twin:      # both samples of every request must be the same computation: [neg0, neg1, pos0, pos1] with equal halves.
+            # ONE fused device comparison and one host sync per call (four torch.equal syncs per request before every call)
+            e_all, t_all = torch.stack(ehs_l), torch.stack(text_l)                   # (n, 4, 77, Cx), (n, 4, P)
+            same = (e_all[:, 0] == e_all[:, 1]).all() & (e_all[:, 2] == e_all[:, 3]).all() & (t_all[:, 0] == t_all[:, 1]).all() & (t_all[:, 2] == t_all[:, 3]).all()
+            twin = bool(same)
         Hl, Wl = lats[0].shape[2:]
         fuse_possible = stage == 2 and Ka > 0 and S > fusion_start + 1
         nm, ncn = 4 * n, 2 * Ka * n                       # rows of the main block / the concept block
@@ -506,7 +555,30 @@ class LoraMultiConceptPipeline:
             for c in active:
                 eng.masks[j][c].copy_(masks_l[j][c])
         xin, nout, step_idx, coef = eng.xin, eng.nout, eng.step_idx, eng.coef
-        cin0 = self.scheduler.cin0(dev)
+        # ---- stage cache: everything that determines the latents entering step fusion_start + 1 of request j
+        first = 0
+        cache_keys: List[str] = []
+        if stage_cache is not None and shard is None and S > fusion_start + 1:
+            common = (S, float(guidance_scale), type(self.scheduler).__name__, fusion_start, height, width, tuple(original_size),
+                      tuple(crops_coords_top_left), tuple(target_size), str(dt), tuple(main_adapters), main_scale, lora_mode if main_adapters else None,
+                      id(self.unet), getattr(bank, "version", None) if main_adapters else None,
+                      None if controller is None else (type(controller).__name__, getattr(controller, "is_pure_replacement", False),
+                                                       getattr(controller, "num_self_replace", None)),
+                      None if not use_cn else (id(controlnet), float(controlnet_conditioning_scale)))
+            for j in range(n):
+                cn_img = None if not use_cn else (controlnet_image if controlnet_image.shape[0] == 1 else controlnet_image[j: j + 1])
+                cache_keys.append(StageCache.digest(common, coef, lats[j], ehs_l[j], text_l[j], cn_img))
+            hit = [stage_cache.get(k) for k in cache_keys]
+            if fuse_possible and all(h is not None for h in hit):
+                first = fusion_start + 1                                 # every request resumes: the plain steps are not run at all
+                lat.copy_(torch.cat([h.to(dev) for h in hit], dim=0))
+                step_idx.fill_(first)
+                if controller is not None:
+                    controller.cur_step = first                          # the host-side counters the skipped steps would have ticked
+                stage_cache.hits += n
+            else:
+                stage_cache.misses += n
+        cin0 = self.scheduler.cin0(dev) if first == 0 else torch.tensor([self.scheduler.cin[first]], dtype=torch.float32, device=dev)
         for j in range(n):
             ops.scale_model_input(lat[2 * j: 2 * j + 2], cin0, xin[4 * j: 4 * j + 4])
         main_kw = dict(cross_attention_kwargs or {})
@@ -731,10 +803,13 @@ class LoraMultiConceptPipeline:
             g.replay()
 
         # ---- 8. denoising loop
-        for i in range(S):
+        for i in range(first, S):
             run_step(i)
             if trajectory is not None:
                 trajectory.append(lat.clone().view(n, 2, Cl, Hl, Wl))
+            if cache_keys and first == 0 and i == fusion_start:         # the latents entering the first fused step of a stage-2 call
+                for j, k in enumerate(cache_keys):
+                    stage_cache.put(k, lat[2 * j: 2 * j + 2])
         return lat.clone().view(n, 2, Cl, Hl, Wl)
 
 
@@ -762,7 +837,12 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                  controlnet_conditioning_scale: float = 1.0, t2i_controlnet_conditioning_scale: float = 1.0, controller=None,
                  concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None, region_masks=None,
                  region_prompt_embeds=None, region_image_embeds=None, output_type: str = "pil", return_dict: bool = True,
-                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, dedup: bool = False, **kwargs):
+                 use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, dedup: bool = False,
+                 cross_attention_kwargs=None, main_adapters=None, concept_adapters=None, lora_mode: str = "merged", **kwargs):
+        """``main_adapters`` / ``concept_adapters`` [(name, weight)]: LoRA adapters of ``concept_models.bank`` that PEFT would have active
+        on the main / the concept pipe (inference_instantid.py:220-222 loads a style LoRA into both; nothing deactivates it).  The main
+        UNet is called with ``cross_attention_kwargs`` (its ``"scale"`` is the LoRA scale, :596-616), the concept UNet with
+        ``cross_attention_kwargs=None`` (:665-674): LoRA scale 1.0."""
         if prompt_embeds is None:
             raise L.OmgHipError("pass prompt_embeds=/pooled_prompt_embeds= (text encoders are outside this package's scope)")
         K = len(region_prompt_embeds or [])
@@ -779,7 +859,10 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                                  fusion_start=fusion_start, identitynet=self.controlnet if use_idn else None,
                                  identitynet_conditioning_scale=controlnet_conditioning_scale,
                                  controlnet=self.controlnet2 if t2i_image is not None else None, controlnet_image=t2i_image,
-                                 controlnet_conditioning_scale=t2i_controlnet_conditioning_scale, dedup=dedup, concept_lora=False)[0]
+                                 controlnet_conditioning_scale=t2i_controlnet_conditioning_scale, dedup=dedup, concept_lora=False,
+                                 cross_attention_kwargs=cross_attention_kwargs, main_adapters=main_adapters,
+                                 concept_adapters=concept_adapters, concept_adapter_scale=1.0, lora_mode=lora_mode,
+                                 stage_cache=kwargs.pop("stage_cache", None))[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         lat = self._postprocess(lat, output_type)

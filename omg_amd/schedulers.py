@@ -52,12 +52,21 @@ class _Base:
     cin: np.ndarray
 
     def coef_table(self, device) -> torch.Tensor:
+        """(n, 4) fp32 per-step coefficients [c_x, c_eps, c_in of the NEXT step, 0] on ``device``.  Cached per device, keyed by the BYTES of
+        the host table: a re-configured scheduler (other betas / spacing / step count) gets a new table, an unchanged one costs no
+        host-to-device copy per call (the table was rebuilt and copied on every pipeline call)."""
         n = self.num_inference_steps
         tab = np.zeros((n, 4), dtype=np.float64)
         tab[:, 0], tab[:, 1] = self.cx, self.ce
         tab[:-1, 2] = self.cin[1:]
         tab[-1, 2] = 1.0
-        return torch.from_numpy(tab.astype(np.float32)).to(device)
+        host = tab.astype(np.float32)
+        key = (str(device), host.tobytes())
+        cached = self.__dict__.get("_coef_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, torch.from_numpy(host).to(device))
+            self._coef_cache = cached
+        return cached[1]
 
     def cin0(self, device) -> torch.Tensor:
         return torch.tensor([self.cin[0]], dtype=torch.float32, device=device)

@@ -259,6 +259,51 @@ class CrossAttnUpBlock2D(_UpBlock):
     pass
 
 
+MX8_CLASSES = ("qkv", "attn_out", "cross_q", "cross_out", "geglu", "ff_out", "proj_in", "proj_out", "conv1", "conv2")
+# round 4: which classes run on the MX-fp8 MFMA under `precision "mx8"`.  From the per-class sensitivity sweep of
+# tools/mx8_sensitivity.py (profiles/r04_mx8_sensitivity.json: 50-step loop error of each class alone in fp8): the classes listed in
+# MX8_MIXED stay fp8, the others return to fp16.
+MX8_MIXED = MX8_CLASSES
+
+
+def mx8_class_of(name: str, module) -> Optional[str]:
+    """The MX-fp8 layer class of a module of the UNet / ControlNet (None: never eligible — conv_in / conv_out, up / down-sampling and
+    shortcut convolutions, the K / V projections of the text context, time / text embeddings: SURVEY §7.3 item 8)."""
+    if isinstance(module, Linear) and ".attentions." in name:
+        for suffix, cls in ((".attn1.to_q", "qkv"), (".attn1.to_k", "qkv"), (".attn1.to_v", "qkv"), (".attn1.to_out.0", "attn_out"),
+                            (".attn2.to_q", "cross_q"), (".attn2.to_out.0", "cross_out"), (".ff.net.0.proj", "geglu"), (".ff.net.2", "ff_out"),
+                            (".proj_in", "proj_in"), (".proj_out", "proj_out")):
+            if name.endswith(suffix):
+                return cls if module.in_features % 128 == 0 else None
+        return None
+    if isinstance(module, Conv2d) and ".resnets." in name and (name.endswith(".conv1") or name.endswith(".conv2")):
+        return name[-5:]
+    return None
+
+
+def set_mx8_classes(net, classes, select=None) -> int:
+    """Put exactly the layer classes in ``classes`` (names of MX8_CLASSES; empty = everything 16-bit) of ``net`` (UNet or ControlNet) on
+    the block-scaled fp8 MFMA.  ``select(name, cls) -> bool`` (optional) narrows further, e.g. to keep the first / last transformer
+    block of a resolution in 16 bits.  Producers follow their consumers (LayerNorm / GroupNorm + SiLU / the GEGLU epilogue write the
+    MX-fp8 operand when the layer they feed is fp8).  Returns the number of fp8 layers."""
+    classes = set(classes or ())
+    unknown = classes - set(MX8_CLASSES)
+    if unknown:
+        raise ValueError(f"unknown MX-fp8 layer classes {sorted(unknown)}; known: {MX8_CLASSES}")
+    changed, n_on = False, 0
+    for name, m in net.named_modules():
+        if not isinstance(m, (Linear, Conv2d)):
+            continue
+        cls = mx8_class_of(name, m)
+        new = cls is not None and cls in classes and (select is None or bool(select(name, cls)))
+        changed |= bool(getattr(m, "mx8", False)) != new
+        m.mx8 = new
+        n_on += int(new)
+    if changed:      # step graphs captured under the other precision launch the other kernels: drop them (pipeline.run_step)
+        bump_pointer_epoch()
+    return n_on
+
+
 class UNet2DConditionModel(nn.Module):
     def __init__(self, config: Optional[UNetConfig] = None, dtype: torch.dtype = torch.float16, device=None):
         super().__init__()
@@ -398,6 +443,14 @@ class UNet2DConditionModel(nn.Module):
         self.conv_precision = mode
         if changed:
             bump_pointer_epoch()
+
+    def set_precision_classes(self, classes, select=None) -> int:
+        """Per-class MX-fp8 map (:func:`set_mx8_classes`); ``set_linear_precision("mx8")`` + ``set_conv_precision("mx8")`` = every class."""
+        n = set_mx8_classes(self, classes, select)
+        cl = set(classes or ())
+        self.linear_precision = "mx8" if cl - {"conv1", "conv2"} else "fp16"
+        self.conv_precision = "mx8" if cl & {"conv1", "conv2"} else "fp16"
+        return n
 
     # ------------------------------------------------------------------ LoRA selection
     def set_lora_state(self, state: Optional[LoraState]) -> None:

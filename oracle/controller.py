@@ -23,6 +23,8 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
+from .precision import r as _r
+
 MAX_WORDS = 77
 
 
@@ -213,9 +215,11 @@ def reference_attn_fn(controller):
             return t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(B * heads, t.shape[1], d)
 
         qb, kb, vb = h2b(q), h2b(k), h2b(v)
-        probs = torch.softmax(torch.baddbmm(torch.empty(()), qb, kb.transpose(-1, -2), beta=0, alpha=d ** -0.5), dim=-1)
+        # oracle.precision: identity by default; under rounding(fp16) the scores, the probabilities and the output are STORED in fp16
+        # as get_attention_scores' baddbmm / softmax and the processor's bmm store them (lora_pipeline.py:114-116)
+        probs = _r(torch.softmax(_r(torch.baddbmm(torch.empty(()), qb, kb.transpose(-1, -2), beta=0, alpha=d ** -0.5)), dim=-1))
         probs = controller(probs, is_cross, "unet")
-        o = torch.bmm(probs, vb)
+        o = _r(torch.bmm(probs, vb))
         return o.reshape(B, heads, N, d).permute(0, 2, 1, 3).reshape(B, N, C)
 
     return fn

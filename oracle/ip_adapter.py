@@ -28,13 +28,19 @@ def _sdpa(q, k, v, heads):
     return (p @ split(v)).permute(0, 2, 1, 3).reshape(B, N, C)
 
 
-def ip_cross_attention(hidden, ctx, to_q, to_k, to_v, to_out_w, to_out_b, to_k_ip, to_v_ip, heads, scale, num_tokens):
+def ip_cross_attention(hidden, ctx, to_q, to_k, to_v, to_out_w, to_out_b, to_k_ip, to_v_ip, heads, scale, num_tokens, lora=None, name=""):
+    """``lora(key, x) -> delta`` (optional): a PEFT adapter wraps the Attention's OWN Linear modules, so ``attn.to_q`` / ``to_k`` / ``to_v``
+    (on the text tokens) / ``to_out[0]`` carry it when the processor calls them (attention_processor.py:372-417); the processor's
+    ``to_k_ip`` / ``to_v_ip`` are not LoRA targets."""
+    def lin(key, x, w, b=None):
+        y = F.linear(x, w, b)
+        return y if lora is None else y + lora(f"{name}.{key}", x)
     end = ctx.shape[1] - num_tokens
     text, ip = ctx[:, :end], ctx[:, end:]
-    q = F.linear(hidden, to_q)
-    o = _sdpa(q, F.linear(text, to_k), F.linear(text, to_v), heads)
+    q = lin("to_q", hidden, to_q)
+    o = _sdpa(q, lin("to_k", text, to_k), lin("to_v", text, to_v), heads)
     o = o + scale * _sdpa(q, F.linear(ip, to_k_ip), F.linear(ip, to_v_ip), heads)
-    return F.linear(o, to_out_w, to_out_b)
+    return lin("to_out.0", o, to_out_w, to_out_b)
 
 
 def self_attention(hidden, to_q, to_k, to_v, to_out_w, to_out_b, heads):
@@ -51,10 +57,10 @@ def make_ip_attn_fn(ip_weights, scale: float, num_tokens: int, base_attn_fn=None
     def fn(name, heads, q, k, v, is_cross):
         return (base_attn_fn or ou.plain_attention)(name, heads, q, k, v, is_cross)
 
-    def cross(sd, name, heads, x, ctx):
+    def cross(sd, name, heads, x, ctx, lora=None):
         wk, wv = ip_weights[name]
         return ip_cross_attention(x, ctx, sd[name + ".to_q.weight"], sd[name + ".to_k.weight"], sd[name + ".to_v.weight"],
-                                  sd[name + ".to_out.0.weight"], sd[name + ".to_out.0.bias"], wk, wv, heads, scale, num_tokens)
+                                  sd[name + ".to_out.0.weight"], sd[name + ".to_out.0.bias"], wk, wv, heads, scale, num_tokens, lora=lora, name=name)
 
     fn.cross_override = cross
     return fn

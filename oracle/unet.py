@@ -17,6 +17,9 @@ full-width topology (2,567,463,684 — the published SDXL-base UNet size, checke
 tests/test_oracle.py) and (ii) the reference's own call sites.  State-dict keys follow the
 diffusers layout so that a real checkpoint would load.
 
+Storage-precision emulation (round 4): inside ``with oracle.precision.rounding(torch.float16):`` every op's output is rounded to
+fp16 as the reference's fp16 eager execution does (fp32 accumulation inside the op): the "fp16 oracle" of DESIGN §3.
+
 Everything is functional over a plain ``dict[str, Tensor]`` (NCHW, fp32); the attention inner
 step is delegated to a pluggable ``attn_fn`` so that the reference's processor + controller
 sequence (oracle/attention.py) can be injected exactly where diffusers would call it.
@@ -29,6 +32,8 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
+
+from .precision import r as _r          # identity unless `with oracle.precision.rounding(torch.float16)` (storage-precision emulation)
 
 Tensor = torch.Tensor
 
@@ -191,32 +196,36 @@ def timestep_embedding(t: Tensor, dim: int) -> Tensor:
     half = dim // 2
     exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
     emb = t.float()[:, None] * torch.exp(exponent)[None, :]
-    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+    return _r(torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1))      # diffusers: computed in fp32, `.to(dtype=sample.dtype)`
 
 
 def _linear(sd, name, x):
-    return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+    return _r(F.linear(x, sd[name + ".weight"], sd.get(name + ".bias")))
 
 
 def _conv(sd, name, x, stride=1, padding=1):
-    return F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=padding)
+    return _r(F.conv2d(x, sd[name + ".weight"], sd[name + ".bias"], stride=stride, padding=padding))
 
 
 def _gn(sd, name, x, groups, eps):
-    return F.group_norm(x, groups, sd[name + ".weight"], sd[name + ".bias"], eps)
+    return _r(F.group_norm(x, groups, sd[name + ".weight"], sd[name + ".bias"], eps))
 
 
 def _ln(sd, name, x):
-    return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5)
+    return _r(F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5))
+
+
+def _silu(x):
+    return _r(F.silu(x))
 
 
 def resnet_block(sd, name, cfg, x, temb):
-    h = _conv(sd, name + ".conv1", F.silu(_gn(sd, name + ".norm1", x, cfg.norm_num_groups, cfg.norm_eps)))
-    h = h + _linear(sd, name + ".time_emb_proj", F.silu(temb))[:, :, None, None]
-    h = _conv(sd, name + ".conv2", F.silu(_gn(sd, name + ".norm2", h, cfg.norm_num_groups, cfg.norm_eps)))
+    h = _conv(sd, name + ".conv1", _silu(_gn(sd, name + ".norm1", x, cfg.norm_num_groups, cfg.norm_eps)))
+    h = _r(h + _linear(sd, name + ".time_emb_proj", _silu(temb))[:, :, None, None])
+    h = _conv(sd, name + ".conv2", _silu(_gn(sd, name + ".norm2", h, cfg.norm_num_groups, cfg.norm_eps)))
     if (name + ".conv_shortcut.weight") in sd:
         x = _conv(sd, name + ".conv_shortcut", x, padding=0)
-    return x + h
+    return _r(x + h)
 
 
 # attn_fn(name, heads, q, k, v, is_cross) -> (B, N, C); q/k/v are (B, N, C) projections
@@ -231,20 +240,22 @@ def plain_attention(name: str, heads: int, q: Tensor, k: Tensor, v: Tensor, is_c
     def split(t):
         return t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3)
 
-    p = torch.softmax(split(q) @ split(k).transpose(-1, -2) * d ** -0.5, dim=-1)
-    return (p @ split(v)).permute(0, 2, 1, 3).reshape(B, N, C)
+    p = _r(torch.softmax(_r(split(q) @ split(k).transpose(-1, -2) * d ** -0.5), dim=-1))       # emulation: scores and probabilities are stored
+    return _r(p @ split(v)).permute(0, 2, 1, 3).reshape(B, N, C)
 
 
 def attention(sd, name, heads, x, ctx, attn_fn: AttnFn, lora=None):
     is_cross = ctx is not None
     if is_cross and getattr(attn_fn, "cross_override", None) is not None:
-        return attn_fn.cross_override(sd, name, heads, x, ctx)        # e.g. IP-Adapter: own K/V projections for the ip tokens
+        if lora is not None:                                          # e.g. IP-Adapter: own K/V projections for the ip tokens
+            return attn_fn.cross_override(sd, name, heads, x, ctx, lora=lora)
+        return attn_fn.cross_override(sd, name, heads, x, ctx)
     src = ctx if is_cross else x
 
     def proj(n, inp):
         y = _linear(sd, f"{name}.{n}", inp)
         if lora is not None:
-            y = y + lora(f"{name}.{n}", inp)
+            y = _r(y + lora(f"{name}.{n}", inp))
         return y
 
     q, k, v = proj("to_q", x), proj("to_k", src), proj("to_v", src)
@@ -253,18 +264,18 @@ def attention(sd, name, heads, x, ctx, attn_fn: AttnFn, lora=None):
 
 
 def transformer_block(sd, name, heads, x, ctx, attn_fn, lora=None):
-    x = x + attention(sd, name + ".attn1", heads, _ln(sd, name + ".norm1", x), None, attn_fn, lora)
-    x = x + attention(sd, name + ".attn2", heads, _ln(sd, name + ".norm2", x), ctx, attn_fn, lora)
+    x = _r(x + attention(sd, name + ".attn1", heads, _ln(sd, name + ".norm1", x), None, attn_fn, lora))
+    x = _r(x + attention(sd, name + ".attn2", heads, _ln(sd, name + ".norm2", x), ctx, attn_fn, lora))
     h = _ln(sd, name + ".norm3", x)
     ff = _linear(sd, name + ".ff.net.0.proj", h)
     if lora is not None:
-        ff = ff + lora(name + ".ff.net.0.proj", h)
+        ff = _r(ff + lora(name + ".ff.net.0.proj", h))
     val, gate = ff.chunk(2, dim=-1)
-    g = val * F.gelu(gate)
+    g = _r(val * _r(F.gelu(gate)))
     out = _linear(sd, name + ".ff.net.2", g)
     if lora is not None:
-        out = out + lora(name + ".ff.net.2", g)
-    return x + out
+        out = _r(out + lora(name + ".ff.net.2", g))
+    return _r(x + out)
 
 
 def transformer_2d(sd, name, cfg, heads, layers, x, ctx, attn_fn, lora=None):
@@ -274,14 +285,14 @@ def transformer_2d(sd, name, cfg, heads, layers, x, ctx, attn_fn, lora=None):
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     y = _linear(sd, name + ".proj_in", h)
     if lora is not None:
-        y = y + lora(name + ".proj_in", h)
+        y = _r(y + lora(name + ".proj_in", h))
     h = y
     for l in range(layers):
         h = transformer_block(sd, f"{name}.transformer_blocks.{l}", heads, h, ctx, attn_fn, lora)
     y = _linear(sd, name + ".proj_out", h)
     if lora is not None:
-        y = y + lora(name + ".proj_out", h)
-    return y.reshape(B, H, W, C).permute(0, 3, 1, 2) + res
+        y = _r(y + lora(name + ".proj_out", h))
+    return _r(y.reshape(B, H, W, C).permute(0, 3, 1, 2) + res)
 
 
 def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timestep, encoder_hidden_states: Tensor,
@@ -297,11 +308,12 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
     if t.numel() == 1:
         t = t.expand(B)
     c0 = cfg.block_out_channels[0]
-    emb = _linear(sd, "time_embedding.linear_2", F.silu(_linear(sd, "time_embedding.linear_1", timestep_embedding(t, c0))))
+    emb = _linear(sd, "time_embedding.linear_2", _silu(_linear(sd, "time_embedding.linear_1", timestep_embedding(t, c0))))
     time_embeds = timestep_embedding(time_ids.float().flatten(), cfg.addition_time_embed_dim).reshape(B, -1)
     add = torch.cat([text_embeds.float(), time_embeds], dim=-1)
-    emb = emb + _linear(sd, "add_embedding.linear_2", F.silu(_linear(sd, "add_embedding.linear_1", add)))
+    emb = _r(emb + _linear(sd, "add_embedding.linear_2", _silu(_linear(sd, "add_embedding.linear_1", add))))
     ctx = encoder_hidden_states.float()
+    sample = _r(sample)                                   # the pipeline hands the UNet latents in its own dtype (lora_pipeline.py:491-492)
 
     def tap(n, v):
         if taps is not None:
@@ -327,7 +339,7 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
             skips.append(h)
         tap(f"down_blocks.{i}", h)
     if down_block_additional_residuals is not None:
-        skips = [s + r.float() for s, r in zip(skips, down_block_additional_residuals)]
+        skips = [_r(s + res_.float()) for s, res_ in zip(skips, down_block_additional_residuals)]
     h = resnet_block(sd, "mid_block.resnets.0", cfg, h, emb)
     tap("mid_block.resnets.0", h)
     h = transformer_2d(sd, "mid_block.attentions.0", cfg, cfg.attention_head_dim[-1],
@@ -335,7 +347,7 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
     tap("mid_block.attentions.0", h)
     h = resnet_block(sd, "mid_block.resnets.1", cfg, h, emb)
     if mid_block_additional_residual is not None:
-        h = h + mid_block_additional_residual.float()
+        h = _r(h + mid_block_additional_residual.float())
     tap("mid_block", h)
     rev_heads = list(reversed(cfg.attention_head_dim))
     rev_layers = list(reversed(cfg.transformer_layers_per_block))
@@ -352,7 +364,7 @@ def unet_forward(sd: Dict[str, Tensor], cfg: UNetConfig, sample: Tensor, timeste
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", h)
         tap(f"up_blocks.{i}", h)
-    h = F.silu(_gn(sd, "conv_norm_out", h, cfg.norm_num_groups, cfg.norm_eps))
+    h = _silu(_gn(sd, "conv_norm_out", h, cfg.norm_num_groups, cfg.norm_eps))
     return _conv(sd, "conv_out", h)
 
 
@@ -389,7 +401,7 @@ def make_lora(cfg: UNetConfig, names: Sequence[str], rank: int, seed: int, scale
         if key not in w:
             return 0.0
         A, Bm = w[key]
-        return scale * F.linear(F.linear(x, A), Bm)
+        return _r(scale * _r(F.linear(_r(F.linear(x, A)), Bm)))          # PEFT: lora_B(lora_A(x)) * scaling, each an op of its own
 
     return w, fn
 

@@ -108,8 +108,24 @@ def controller_alignment_vectors():
         for m, (S, spec) in enumerate([(50, {"default_": 1.0}), (10, {"default_": 0.6, prompts[1].split(" ")[-1]: (0.2, 0.9)}),
                                        (7, {"default_": (0.1, 0.8), prompts[1].split(" ")[0]: 0.3})]):
             out[f"c{n}_alpha{m}"] = p2p_utils.get_time_words_attention_alpha(prompts, S, dict(spec), tok).numpy()
+    # round 4: prompts LONGER than the 77-token window — `tokenizer.encode` does not truncate, the reference's two-pointer walk
+    # simply stops at 77.  Replaced word exactly at token 77 (the first position outside), beyond it, and just inside.
+    for n, w in enumerate(LONG_REPLACED_WORDS):
+        a, b = long_prompt_pair(w)
+        out[f"long{n}_mapper"] = seq_aligner.get_replacement_mapper([a, b], WhitespaceTokenizer()).numpy()
     np.savez_compressed(os.path.join(HERE, "controller_alignment_golden.npz"), **out)
     print("controller_alignment_golden.npz:", len(out), "arrays")
+
+
+LONG_REPLACED_WORDS = (76, 80, 75, 74)        # word index k is token k + 1 for the whitespace tokenizer (BOS at 0)
+
+
+def long_prompt_pair(k: int, n_words: int = 86):
+    """two prompts of n_words one-token words that differ in word k only"""
+    words = [f"w{i}" for i in range(n_words)]
+    other = list(words)
+    other[k] = "changed"
+    return " ".join(words), " ".join(other)
 
 
 class _FakeAttn(torch.nn.Module):

@@ -1,5 +1,7 @@
 """B3 (-m gpu): the reference's own driver code — ``build_model_sd`` and ``sample_image`` of inference_lora.py (:152-171, :37-73),
-transcribed with ONLY the import block changed — runs against omg_amd.compat on a synthetic model directory, stage 1 and stage 2,
+transcribed verbatim (tests/test_compat_verbatim.py compares the syntax trees with /root/reference where it exists) under the script's
+ORIGINAL import lines (``omg_amd.compat.install()`` registers ``src.pipelines.*``, ``src.prompt_attention.p2p_attention`` and
+``diffusers``) — runs against omg_amd.compat on a synthetic model directory, stage 1 and stage 2,
 with and without a style LoRA and a spatial condition; the result equals the lower-level embeddings-in / latents-out API fed with the
 same encoders' outputs (so the string / PIL surface adds plumbing, not arithmetic)."""
 import os
@@ -12,11 +14,14 @@ pytestmark = pytest.mark.gpu
 
 from tests import _fake_hub as hub
 
-# ---- the import block a maintainer edits -------------------------------------------------------------
-from omg_amd.controller import AttentionReplace                                   # was: from src.prompt_attention.p2p_attention import AttentionReplace
-from omg_amd.compat import ControlNetModel, StableDiffusionXLPipeline              # was: from diffusers import ControlNetModel, StableDiffusionXLPipeline
-from omg_amd.pipeline import revise_regionally_controlnet_forward                  # was: from src.pipelines.lora_pipeline import revise_regionally_controlnet_forward
-from omg_amd.compat import LoraMultiConceptPipeline                                # was: from src.pipelines.lora_pipeline import LoraMultiConceptPipeline
+# ---- the reference's own import lines (inference_lora.py:29-32), UNCHANGED: omg_amd.compat.install() provides the modules ----------------
+from omg_amd import compat as _compat
+_compat.install()
+from src.pipelines.lora_pipeline import LoraMultiConceptPipeline
+from src.prompt_attention.p2p_attention import AttentionReplace
+from diffusers import ControlNetModel, StableDiffusionXLPipeline
+from src.pipelines.lora_pipeline import revise_regionally_controlnet_forward
+_compat.uninstall()          # keep the aliases out of the other test modules of the process; the names above stay bound
 
 
 # ---- inference_lora.py:37-73, unchanged ----------------------------------------------------------------------------------
@@ -59,7 +64,7 @@ def sample_image(pipe,
     return images
 
 
-# ---- inference_lora.py:152-171, unchanged except num_steps of the controller being a parameter of the test -----------------
+# ---- inference_lora.py:150-171, unchanged ---------------------------------------------------------------------------------
 def build_model_sd(pretrained_model, controlnet_path, device, prompts, lora_paths, width, height, style_lora):
     controlnet = ControlNetModel.from_pretrained(controlnet_path, torch_dtype=torch.float16).to(device)
     pipe = LoraMultiConceptPipeline.from_pretrained(

@@ -1,6 +1,7 @@
 """B3 for the SECOND script BASELINE's north_star names (-m gpu): ``sample_image`` (:72-110), ``build_model_sd`` (:186-232),
-``prepare_text`` (:234-255) and the two-stage main flow (:296-366) of the reference's inference_instantid.py, transcribed with only
-the import block changed, run against omg_amd.compat on a synthetic model directory: stage 1 (``image=None`` => no IdentityNet,
+``prepare_text`` (:234-255) and the two-stage main flow (:296-366) of the reference's inference_instantid.py, transcribed verbatim
+(tests/test_compat_verbatim.py compares the syntax trees with /root/reference where it exists) under the script's ORIGINAL import lines
+(``omg_amd.compat.install()``), run against omg_amd.compat on a synthetic model directory: stage 1 (``image=None`` => no IdentityNet,
 instantid_pipeline.py:393, :426-428) and stage 2 (key-point image on every concept pass, face embeddings through
 ``concept_models._encode_prompt_image_emb``, :378-388), with and without ``pipe.controlnet2`` + ``t2i_image`` (:574-616).
 The result equals the embeddings-in API (omg_amd.pipeline.InstantidMultiConceptPipeline) fed with the same encoders' outputs.
@@ -19,12 +20,15 @@ pytestmark = pytest.mark.gpu
 
 from tests import _fake_hub as hub
 
-# ---- the import block a maintainer edits -------------------------------------------------------------
-from omg_amd.controller import AttentionReplace                                   # was: from src.prompt_attention.p2p_attention import AttentionReplace
-from omg_amd.compat import ControlNetModel                                         # was: from diffusers import ControlNetModel
-from omg_amd.compat import InstantidMultiConceptPipeline                           # was: from src.pipelines.instantid_pipeline import InstantidMultiConceptPipeline
-from omg_amd.pipeline import revise_regionally_controlnet_forward                  # was: from src.pipelines.instantid_pipeline import revise_regionally_controlnet_forward
-from omg_amd.compat import StableDiffusionXLInstantIDPipeline as InstantidSingleConceptPipeline   # was: from src.pipelines.instantid_single_pieline import InstantidSingleConceptPipeline
+# ---- the reference's own import lines (inference_instantid.py:12, :34-37), UNCHANGED: omg_amd.compat.install() provides the modules ----
+from omg_amd import compat as _compat
+_compat.install()
+from diffusers import ControlNetModel, StableDiffusionXLPipeline
+from src.pipelines.instantid_pipeline import InstantidMultiConceptPipeline
+from src.pipelines.instantid_single_pieline import InstantidSingleConceptPipeline
+from src.prompt_attention.p2p_attention import AttentionReplace
+from src.pipelines.instantid_pipeline import revise_regionally_controlnet_forward
+_compat.uninstall()          # keep the aliases out of the other test modules of the process; the names above stay bound
 
 
 class FaceAnalysis:
@@ -290,3 +294,60 @@ def test_instantid_driver_code_runs_on_the_compat_objects(dev, hub_dirs, use_pos
                           generator=torch.Generator(device).manual_seed(seed), controller=controller, face_app=face_app, image=face_kps, stage=2,
                           controlnet_conditioning_scale=idn_rate, region_masks=[mask1, mask2], guidance_scale=cfg_scale, num_inference_steps=S, **kwargs)
     assert not np.array_equal(np.array(image3[1]), np.array(image2[1]))
+
+
+def test_a_style_lora_loaded_by_the_script_is_active_on_both_pipes(dev, hub_dirs, tmp_path):
+    """inference_instantid.py:220-222 loads the style LoRA into BOTH pipes and nothing in instantid_pipeline.py ever calls
+    ``set_adapters``: PEFT leaves the freshly loaded adapter switched on, so the reference's images carry it — main rows at the caller's
+    ``cross_attention_kwargs["scale"]`` (0.8 in ``sample_image``, :596-616), concept rows at 1.0 (``cross_attention_kwargs=None``, :665-674),
+    text encoders at ``lora_scale`` = 0.8 (:330-360).  Round 3 loaded the file and ignored it."""
+    from PIL import Image
+    from omg_amd import compat
+    model, idn_dir, pose_dir, ckpt, refs, antelope = hub_dirs
+    compat.clear_component_cache()
+    comp = compat._components(model, torch.float16, None)
+    style = os.path.dirname(hub.write_lora_file(str(tmp_path / "style" / "pytorch_lora_weights.safetensors"), comp.unet, 31, style="peft",
+                                                text_encoders=[comp.text_encoder, comp.text_encoder_2]))
+    device = dev
+    prompt = "a man and a woman walking on the street"
+    prompts = [prompt] * 2
+    width = height = 128
+    S, cfg_scale, idn_rate, seed = 20, 3.0, 0.8, 7
+    rewrite = f"[a man in the park]-*-[painting]-*-{refs[0]}|[a woman in the park]-*-[painting]-*-{refs[1]}"
+    input_prompt = [prompts, prepare_text(prompt, rewrite)[1]]
+    mask1 = torch.zeros(height, width, dtype=torch.bool); mask1[32:, 8:60] = True
+    mask2 = torch.zeros(height, width, dtype=torch.bool); mask2[32:, 56:120] = True
+    kps = Image.fromarray((np.random.RandomState(6).rand(height, width, 3) * 255).astype("uint8"))
+    kwargs = {'height': height, 'width': width, 't2i_image': None, 't2i_controlnet_conditioning_scale': 0.7}
+    out = {}
+    for tag, style_dir in (("plain", None), ("style", style)):
+        compat.clear_component_cache()
+        pipe, controller, pipe_concepts, face_app = build_model_sd(model, idn_dir, ckpt, device, list(prompts), antelope, width // 32, height // 32,
+                                                                   style_dir, None, 0.8)
+        assert pipe.peft_active_adapters() == ([("style", 1.0)] if style_dir else []) == pipe_concepts.peft_active_adapters()
+        out[tag] = sample_image(pipe, input_prompt=input_prompt, concept_models=pipe_concepts, input_neg_prompt=["painting"] * 2,
+                                generator=torch.Generator(device).manual_seed(seed), controller=controller, face_app=face_app, image=kps, stage=2,
+                                controlnet_conditioning_scale=idn_rate, region_masks=[mask1, mask2], guidance_scale=cfg_scale,
+                                num_inference_steps=S, **kwargs)
+    a, b = np.array(out["plain"][1]).astype(int), np.array(out["style"][1]).astype(int)
+    assert np.abs(a - b).max() > 3, "the style adapter changes the image (it was silently ignored in round 3)"
+    assert np.abs(np.array(out["plain"][0]).astype(int) - np.array(out["style"][0]).astype(int)).max() > 3, "... on the base sample too (main rows)"
+
+    # ---- the same call through the embeddings-in API with the adapters named explicitly (pipe / pipe_concepts are the style build)
+    from omg_amd.pipeline import InstantidMultiConceptPipeline as LowLevel
+    regions = input_prompt[1]
+    pe, ne, pp, npp = pipe.encode_prompt(list(prompts) + [r[0] for r in regions], ["painting"] * 2 + [r[1] for r in regions], [("style", 1.0)], 0.8)
+    pe0 = pipe.encode_prompt(list(prompts), ["painting"] * 2, None, 0.8)[0]
+    assert not torch.equal(pe0, pe[:2]), "the adapter's text-encoder half acts while the prompts are encoded"
+    tokens = [pipe_concepts._encode_prompt_image_emb(e, pipe_concepts._execution_device, 1, pipe.unet.dtype, True)
+              for e in compat.get_face_embedding(face_app, [r[2] for r in regions])]
+    low = LowLevel(pipe.unet, pipe.controlnet, type(pipe.scheduler)(), vae_decode=pipe.vae.decode_latents)
+    controller.reset()
+    to_t = lambda im: torch.from_numpy(np.asarray(im.convert("RGB").resize((width, height))).astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    ref = low(prompt_embeds=pe[:2], negative_prompt_embeds=ne[:2], pooled_prompt_embeds=pp[:2], negative_pooled_prompt_embeds=npp[:2],
+              region_prompt_embeds=[(ne[2 + c: 3 + c], pe[2 + c: 3 + c], npp[2 + c: 3 + c], pp[2 + c: 3 + c]) for c in range(2)],
+              region_image_embeds=tokens, image=to_t(kps), height=height, width=width, num_inference_steps=S, guidance_scale=cfg_scale,
+              generator=torch.Generator(device).manual_seed(seed), controlnet_conditioning_scale=idn_rate, controller=controller,
+              concept_models=pipe_concepts, stage=2, region_masks=[mask1, mask2], output_type="pil",
+              cross_attention_kwargs={"scale": 0.8}, main_adapters=[("style", 1.0)], concept_adapters=[("style", 1.0)]).images
+    assert np.array_equal(np.array(ref[1]), np.array(out["style"][1]))

@@ -109,6 +109,18 @@ def test_alignment_tables_match_reference_generated_vectors(n):
         assert np.array_equal(pc.get_time_words_attention_alpha(prompts, S, dict(spec), tok).numpy(), gold[f"c{n}_alpha{m}"]), (n, m)
 
 
+@pytest.mark.parametrize("n,k", list(enumerate((76, 80, 75, 74))))
+def test_alignment_of_prompts_longer_than_the_token_window(n, k):
+    """a replaced word reached exactly where the 77-token window ends (or beyond it) made the run-offset construction index
+    row 77; the reference's two-pointer walk stops there and returns the matrix.  Vectors from the reference's own seq_aligner
+    (tests/golden/make_golden.py: LONG_REPLACED_WORDS, 86-word prompts on the whitespace tokenizer).  Bit-exact."""
+    gold = np.load(os.path.join(GOLD, "controller_alignment_golden.npz"))
+    words = [f"w{i}" for i in range(86)]
+    other = list(words); other[k] = "changed"
+    got = pc.get_replacement_mapper([" ".join(words), " ".join(other)], oc.WhitespaceTokenizer()).numpy()
+    assert np.array_equal(got, gold[f"long{n}_mapper"])
+
+
 @pytest.mark.parametrize("n", [50, 30, 10])
 def test_scheduler_tables_reproduce_the_oracle_schedulers(n):
     rng = np.random.default_rng(0)

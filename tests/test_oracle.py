@@ -209,3 +209,46 @@ def test_resampler_oracle_matches_reference_golden():
     # InstantID's configuration (instantid_single_pieline.py:165-174): 16 tokens of 2048 from one 512-d embedding
     full = orr.param_shapes(1280, 4, 64, 20, 16, 512, 2048, 4)
     assert full["latents"] == (1, 16, 1280) and full["proj_out.weight"] == (2048, 1280) and full["layers.3.1.3.weight"] == (1280, 5120)
+
+
+def test_storage_precision_emulation_of_the_oracle_unet():
+    """oracle/precision.py (round 4): inside ``rounding(torch.float16)`` every op's output is rounded as the reference's fp16 eager run
+    rounds it; outside, the oracle is bit for bit the fp32 function it was.  Facts checked: (i) no state leaks out of the context;
+    (ii) the emulated output is fp16-representable and differs from fp32 by ~1e-3 of the output rms (fp16 has 11 significant bits, ~60
+    chained layers) — not by 0 (the hook would be dead) and not by 1e-1 (it would be broken); (iii) bf16 is coarser than fp16;
+    (iv) with the controller's attention sequence the rounding reaches the probabilities the controller edits."""
+    from oracle import precision as oprec
+    cfg = ounet.UNetConfig.tiny()
+    sd = ounet.init_state_dict(cfg, seed=0, dtype=torch.float16)
+    B, L = 4, cfg.sample_size
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 4, L, L, generator=g)
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim, generator=g).half().float()
+    te = torch.randn(B, 64, generator=g).half().float()
+    tid = torch.tensor([[L * 8, L * 8, 0, 0, L * 8, L * 8]] * B, dtype=torch.float32)
+    names = ounet.lora_target_names(cfg)
+    _, lora = ounet.make_lora(cfg, names, rank=4, seed=3, scale=0.8, dtype=torch.float16)
+
+    def run(attn=None):
+        kw = {} if attn is None else {"attn_fn": attn}
+        return ounet.unet_forward(sd, cfg, x, 981, ctx, te, tid, lora=lora, **kw)
+
+    y32 = run()
+    with oprec.rounding(torch.float16):
+        assert oprec.active() == torch.float16
+        y16 = run()
+    with oprec.rounding(torch.bfloat16):
+        yb = run()
+    assert oprec.active() is None and torch.equal(run(), y32)
+    assert torch.equal(y16, y16.half().float())
+    rms = y32.pow(2).mean().sqrt()
+    e16, eb = ((y16 - y32).pow(2).mean().sqrt() / rms).item(), ((yb - y32).pow(2).mean().sqrt() / rms).item()
+    assert 1e-4 < e16 < 1e-2 and e16 < eb < 1e-1, (e16, eb)
+    c = oc.AttentionReplaceOracle([P, P], 50, {"default_": 1.0}, 0.4, L // 4, L // 4)
+    c.num_att_layers = 2 * ounet.count_attention_layers(cfg)
+    yc32 = run(oc.reference_attn_fn(c))
+    c.reset()
+    with oprec.rounding(torch.float16):
+        yc16 = run(oc.reference_attn_fn(c))
+    ec = ((yc16 - yc32).pow(2).mean().sqrt() / yc32.pow(2).mean().sqrt()).item()
+    assert 1e-4 < ec < 1e-2, ec

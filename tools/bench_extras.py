@@ -105,6 +105,32 @@ if a.what in ("ips", "both"):
         print(json.dumps({"measurement": "stage1_plus_stage2", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec, "sec_per_step": sec,
                           "workload": "BASELINE configs[1]: stage 1 (50 plain steps, decode) + stage 2 (fusion for i > 15, decode) per image; "
                                       "detection / segmentation between the stages excluded; 3.626 PFLOP per image (SURVEY 8d)", "steps_timed": a.steps}), flush=True)
+        # ---- the same two calls with the exact redundancies of SURVEY 7.4 taken out (round 4): stage 1 runs [unc, cond] once per request
+        # (dedup), stage 2 resumes at the first fused step from the latents stage 1 left in the StageCache and keeps dedup off (nothing
+        # left to deduplicate): 100 + 272 = 372 of the reference's 536 sample-forwards; latents compared bitwise with the full flow
+        from omg_amd.pipeline import StageCache
+        last = {}
+        def both_dedup(i):
+            rq = reqs_for(n, i)
+            cache = StageCache()
+            ctl.reset()
+            lat1 = pipe.generate_many([{k: v for k, v in r.items() if k != "region_masks"} for r in rq], stage=1, dedup=True, stage_cache=cache, **kw)
+            for j in range(n):
+                vae.decode_latents(lat1[j])
+            ctl.reset()
+            lat2 = pipe.generate_many(rq, stage=2, stage_cache=cache, **kw)
+            assert cache.hits == n, (cache.hits, cache.misses)
+            for j in range(n):
+                vae.decode_latents(lat2[j])
+            last["lat"], last["i"] = lat2, i
+        sec_d = timed(both_dedup, a.steps)
+        ctl.reset()
+        want = pipe.generate_many(reqs_for(n, last["i"]), stage=2, **kw)
+        print(json.dumps({"measurement": "stage1_plus_stage2_dedup", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec_d, "sec_per_step": sec_d,
+                          "sample_forwards_executed": 372, "sample_forwards_reference": 536, "latents_bitwise_equal_to_full_flow": bool(torch.equal(want, last["lat"])),
+                          "workload": "the same flow with SURVEY 7.4's exact redundancies removed: stage 1 deduplicated ([unc, cond] once per request: 100 "
+                                      "sample-forwards), stage 2 resumed at step 16 from the stage-1 latents (StageCache: 34 x 8 = 272); both decodes kept",
+                          "steps_timed": a.steps}), flush=True)
 elif a.what == "config4":
     from omg_amd.controlnet import ControlNetModel
     cn = random_init_(ControlNetModel(UNetConfig.sdxl(), dtype=dt, device=dev), 7)
