@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="stop at the latents (skip the VAE decode that ends the reference's stage-2 call)")
     ap.add_argument("--vae-16bit", action="store_true", help="decode in bf16 storage instead of the reference's fp32 up blocks (faster, NOT the reference's precision)")
     ap.add_argument("--fp8-linear-only", action="store_true", help="with --dtype fp8: keep every convolution in fp16 (round-2 first fp8 line)")
+    ap.add_argument("--fp8-classes", default="all", help="with --dtype fp8: which layer classes run on the MX-fp8 MFMA — a preset of omg_amd.unet.MX8_PRESETS "
+                    "(all | safe | none) or a comma list of omg_amd.unet.MX8_CLASSES (profiles/r04_mx8_sensitivity.json is the per-class error table)")
     ap.add_argument("--no-power", action="store_true", help="do not poll rocm-smi for power / clock during the timed region")
     ap.add_argument("--no-graph", action="store_true", help="run the step loop eagerly instead of replaying captured hipGraphs")
     ap.add_argument("--shard", default="images", choices=["images", "concept"],
@@ -188,10 +190,13 @@ def main():
 
     cfg = UNetConfig.tiny() if args.tiny else UNetConfig.sdxl()
     unet = UNet2DConditionModel(cfg, dtype=dt, device=dev).init_synthetic_(seed=0)
+    fp8_classes = ()
     if args.dtype == "fp8":
-        unet.set_linear_precision("mx8")
-        if not args.fp8_linear_only:
-            unet.set_conv_precision("mx8")
+        from omg_amd.unet import MX8_PRESETS
+        fp8_classes = tuple(MX8_PRESETS[args.fp8_classes]) if args.fp8_classes in MX8_PRESETS else tuple(c for c in args.fp8_classes.split(",") if c)
+        if args.fp8_linear_only:
+            fp8_classes = tuple(c for c in fp8_classes if not c.startswith("conv"))
+        unet.set_precision_classes(fp8_classes)
     HW = cfg.sample_size * 8
     P = "a man and a woman walking on the street"
     ctl = pc.AttentionReplace([P, P], 50, cross_replace_steps={"default_": 1.0}, self_replace_steps=0.4,
@@ -291,9 +296,10 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * el / args.steps,
            "value_dedup": dedup["value"] if dedup else None, "dedup": dedup,
            "higher_is_better": True, "scaling": "strong" if by_concept else "weak", "vs_baseline": None,
-           "dtype": ("fp8 (OCP MX e4m3 operands, fp32 accumulate) on the transformer Linear layers" + ("" if args.fp8_linear_only else " and the resnet 3x3 convolutions with Cin % 128 == 0")
+           "dtype": ("fp8 (OCP MX e4m3 operands, fp32 accumulate) on the layer classes " + "+".join(fp8_classes)
                      + "; fp16 elsewhere; measured loop tolerance vs the fp32 oracle (50-step stage-2 trajectory, random-weight SDXL topology at reduced width: "
-                       "profiles/r03_error_growth_mx8.json): rms error 0.10, max 0.40 of the latent rms, flat after step 10 (fp16 path: 1.5e-3 / 5.3e-3)") if args.dtype == "fp8" else args.dtype,
+                       "profiles/r04_mx8_sensitivity.json, r04_error_growth_mx8.json): every class: rms error 0.10, max 0.40 of the latent rms, flat after step 10; "
+                       "preset 'safe' (cross_q+cross_out+ff_out): rms 0.031, max 0.11; fp16 path: 1.5e-3 / 5.3e-3; no class dominates — the ten add in quadrature") if args.dtype == "fp8" else args.dtype,
            "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: SDXL-base 1024x1024, %d %s steps, 2 concepts + 2 rank-64 LoRAs, masked "
                                   "attention fusion (i>15), p2p controller; one stage-2 call per image (masks given)" % (args.denoise_steps, args.scheduler.upper()),

@@ -7,7 +7,7 @@
 
   config4  BASELINE configs[4]: OMG + ControlNet (openpose-sdxl architecture, on the main pass of every step) + 3 concepts + style LoRA
            (main pass, and [0.7, 0.5] with each concept), 1024^2, 50 DDIM steps; --dtype fp8 = the config's arithmetic (MX-fp8 on the
-           UNet's transformer Linears and resnet convolutions; the ControlNet stays fp16): 3.337 PFLOP per image
+           transformer Linears and resnet convolutions of the UNet and, round 4, of the ControlNet): 3.337 PFLOP per image
 
 python tools/bench_extras.py ips|both|instantid|config4 [--steps K] [--dtype fp16|fp8]   -> one JSON line per measurement
 """
@@ -134,6 +134,9 @@ if a.what in ("ips", "both"):
 elif a.what == "config4":
     from omg_amd.controlnet import ControlNetModel
     cn = random_init_(ControlNetModel(UNetConfig.sdxl(), dtype=dt, device=dev), 7)
+    if a.dtype == "fp8":      # round 4: BASELINE configs[4] says "fp8 MFMA" for the step — the ControlNet of the main pass included
+        from omg_amd.unet import MX8_CLASSES
+        cn.set_precision_classes(MX8_CLASSES)
     concept = make_concept_models(unet, n_concepts=3, rank=64, style=True)
     pipe = LoraMultiConceptPipeline(unet, make_scheduler("ddim"))
     m3 = torch.zeros(1024, 1024, device=dev); m3[128:512, 300:700] = 1
@@ -163,7 +166,7 @@ elif a.what == "config4":
                       "end_to_end_tflops": pf * 1e3 * n / sec,
                       "workload": "BASELINE configs[4]: SDXL 1024^2, 50 DDIM steps, ControlNet (openpose-sdxl architecture, 1.25 B parameters) on the main pass, 3 concepts "
                                   "with overlapping masks, style LoRA on the main pass and [0.7, 0.5] with each concept LoRA, stage-2 call + upcast VAE decode; "
-                                  "3.337 PFLOP per image (SURVEY 8d); fp8 = MX-fp8 on the UNet's transformer Linears + resnet convolutions, ControlNet fp16",
+                                  "3.337 PFLOP per image (SURVEY 8d); fp8 = MX-fp8 on the transformer Linears + resnet convolutions of the UNet AND (round 4) of the ControlNet",
                       "steps_timed": a.steps}), flush=True)
 else:
     from omg_amd.controlnet import ControlNetModel

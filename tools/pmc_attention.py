@@ -32,7 +32,7 @@ def one_pass(counters, cmd, match):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_pmc_attention.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_pmc_attention.json")
     sq = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]
     rec = {"method": __doc__}
     for name, shape, match in (("self", (64, 10, 4096, 4096), "attn_fwd_kernel3"), ("cross", (64, 20, 1024, 77), "attn_fwd_kernel6")):
