@@ -547,7 +547,7 @@ class LoraMultiConceptPipeline:
         eng.emb_main.copy_(emb_main)
         coef_now = self.scheduler.coef_table(dev)          # per call: the key holds the scheduler's class and step count, not its
         if eng.coef is None:                               # configuration — a re-configured scheduler must not meet a cached table
-            eng.coef = coef_now
+            eng.coef = coef_now.clone()                    # the engine's OWN buffer: the scheduler's cached table is shared and read-only
         else:
             eng.coef.copy_(coef_now)                       # in place: captured graphs keep the pointer
         eng.step_idx.zero_()
