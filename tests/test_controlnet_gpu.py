@@ -37,7 +37,7 @@ def test_controlnet_and_unet_residual_path(dev):
         err = (a.float().cpu() - b).abs().max().item()
         assert err < 2e-2, f"residual {i}: {err}"
     # cached conditioning embedding: second call must not recompute and must be identical
-    down2, _ = cn(x.to(dev), 981, encoder_hidden_states=ctx.to(dev).to(dtype), controlnet_cond=cn._cond_cache[2], conditioning_scale=0.8,
+    down2, _ = cn(x.to(dev), 981, encoder_hidden_states=ctx.to(dev).to(dtype), controlnet_cond=next(iter(cn._cond_cache.values()))[2], conditioning_scale=0.8,
                   added_cond_kwargs=added)
     assert torch.equal(down2[0], down[0])
     y = unet(x.to(dev), 981, encoder_hidden_states=ctx.to(dev).to(dtype), added_cond_kwargs=added,

@@ -1,7 +1,11 @@
 #!/bin/bash
-# full GPU suite + headline bench (round-end rehearsal)
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q --durations=12 > gpurun_out/r03_pytest_gpu.log 2>&1
-tail -25 gpurun_out/r03_pytest_gpu.log
-python bench.py --gpus 1 --steps ${STEPS:-20} --warmup ${WARMUP:-5} > gpurun_out/r03_bench_fp16_${TAG:-v2}.json 2> gpurun_out/r03_bench_fp16_${TAG:-v2}.err
-head -c 600 gpurun_out/r03_bench_fp16_${TAG:-v2}.json
+# full GPU suite + headline bench (round-end rehearsal):   gpurun --timeout 3600 -- 'bash tools/gpu_round_end.sh'
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04
+mkdir -p $O
+python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest_gpu.log 2>&1
+tail -22 $O/pytest_gpu.log
+python bench.py --gpus 1 --steps ${STEPS:-3} --warmup ${WARMUP:-1} --by-shape $O/by_shape_fp16_${TAG:-v1}.txt > $O/bench_fp16_${TAG:-v1}.json 2> $O/bench_fp16_${TAG:-v1}.err
+head -c 900 $O/bench_fp16_${TAG:-v1}.json; echo
+python bench.py --gpus 1 --steps 2 --warmup 1 --dtype fp8 --no-cpu-baseline --by-shape $O/by_shape_fp8_${TAG:-v1}.txt > $O/bench_fp8_${TAG:-v1}.json 2> $O/bench_fp8_${TAG:-v1}.err
+head -c 500 $O/bench_fp8_${TAG:-v1}.json; echo
