@@ -1,6 +1,7 @@
 """B3 (CPU half): the diffusers-shaped constructors of omg_amd.compat on a synthetic model directory — what from_pretrained /
 load_lora_weights / tokenizer / .to() give the reference's build_model_sd (inference_lora.py:152-171).  Compute needs the GPU."""
 import os
+import sys
 
 import pytest
 import torch
@@ -73,3 +74,23 @@ def test_instantid_container_surface(dirs):
             return [{"bbox": [0, 0, 4, 4], "embedding": "big"}, {"bbox": [0, 0, 1, 1], "embedding": "small"}]
 
     assert compat.get_face_embedding(FakeApp(), [img]) == ["small"]
+
+
+def test_the_module_runner_executes_a_script_under_the_aliases(tmp_path, capsys):
+    """``python -m omg_amd.run script.py args`` = install() + the script's directory on sys.path + runpy: a stand-in script with the
+    reference's own import lines (inference_lora.py:29-32) and an ``if __name__ == "__main__"`` body sees this package's classes and its
+    own arguments."""
+    import subprocess
+    script = tmp_path / "driver.py"
+    script.write_text(
+        "import sys\n"
+        "from src.pipelines.lora_pipeline import LoraMultiConceptPipeline\n"
+        "from src.prompt_attention.p2p_attention import AttentionReplace\n"
+        "from diffusers import ControlNetModel, StableDiffusionXLPipeline\n"
+        "from src.pipelines.lora_pipeline import revise_regionally_controlnet_forward\n"
+        "if __name__ == '__main__':\n"
+        "    print(LoraMultiConceptPipeline.__module__, AttentionReplace.__module__, ControlNetModel.__module__, sys.argv[1:])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "omg_amd.run", str(script), "--prompt", "a man"], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "omg_amd.compat omg_amd.controller omg_amd.compat ['--prompt', 'a man']" in r.stdout

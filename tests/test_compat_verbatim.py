@@ -82,3 +82,4 @@ def test_the_original_import_block_executes_under_compat_install(script, hot, ca
         compat.uninstall()
         sys.path[:] = saved_path
     assert "diffusers" not in sys.modules or not vars(sys.modules["diffusers"]).get("__omg_amd_alias__", False)
+

@@ -163,6 +163,15 @@ def test_schedulers_basic_properties():
     eu = osched.EulerDiscrete(50)
     assert np.all(np.diff(eu.sigmas) < 0) and eu.sigmas[-1] == 0
     assert abs(eu.init_noise_sigma - (eu.sigmas[0] ** 2 + 1) ** 0.5) < 1e-12
+    # externally known constants of the SD / SDXL noise schedule (scaled-linear betas 0.00085 .. 0.012 over 1000 steps): the sigma range
+    # every k-diffusion-style sampler quotes for these checkpoints, sigma_min 0.0292 and sigma_max 14.6146 (recalled from public
+    # documentation, not from a file in /root/reference — an anchor, not a pin), and alphas_cumprod[999] = 0.00466
+    ac = osched.alphas_cumprod()
+    assert abs(((1 - ac[999]) / ac[999]) ** 0.5 - 14.6146) < 1e-3 and abs(((1 - ac[0]) / ac[0]) ** 0.5 - 0.0292) < 1e-4
+    assert abs(ac[999] - 0.00466) < 1e-5
+    from omg_amd.schedulers import EulerDiscreteScheduler
+    mine = EulerDiscreteScheduler(); mine.set_timesteps(50, device="cpu")
+    assert abs(float(mine.alphas_cumprod[999]) - ac[999]) < 1e-12          # the product's own table is the same schedule
 
 
 def test_controlnet_topology_parameter_count():
