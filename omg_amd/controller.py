@@ -262,7 +262,9 @@ class AttentionReplace:
                      device=None, total_batch: Optional[int] = None, images: int = 1) -> Optional[torch.Tensor]:
         if not self.is_pure_replacement:
             raise RuntimeError("fused_qk_src needs a pure-replacement controller (identity mapper, alpha == 1)")
-        if batch != 2 * self.batch_size:
+        if batch not in (2 * self.batch_size, 2 * self.batch_size - 1):
+            # 2 n - 1: the block without the base sample's unconditional row ([unc_1.., cond_0, cond_1..]: pipeline `drop_unc0`) — the same
+            # rule "every conditional row borrows from the first conditional one" with one unconditional row fewer in front
             raise ValueError(f"controller built for {self.batch_size} prompts expects a batch of {2 * self.batch_size} "
                              f"([unc..., cond...]), got {batch}")
         src = self.qk_src_vector(batch, device or self.device or "cuda", total_batch, images) if self.replaces(is_cross, n_tokens) else None

@@ -129,6 +129,7 @@ class StageCache:
 
     def __init__(self, max_entries: int = 64):
         self.entries: Dict[str, torch.Tensor] = {}
+        self.base: Dict[str, Dict[int, Tuple[torch.Tensor, torch.Tensor]]] = {}
         self.max_entries = max_entries
         self.hits = 0
         self.misses = 0
@@ -147,11 +148,28 @@ class StageCache:
 
     def put(self, key: str, latents: torch.Tensor) -> None:
         if key not in self.entries and len(self.entries) >= self.max_entries:
-            self.entries.pop(next(iter(self.entries)))
+            old = next(iter(self.entries))
+            self.entries.pop(old)
+            self.base.pop(old, None)
         self.entries[key] = latents.detach().clone()
 
     def get(self, key: str) -> Optional[torch.Tensor]:
         return self.entries.get(key)
+
+    # ---- the BASE sample's trajectory behind the first fused step (last item): sample 0 of a call is never fused
+    # (lora_pipeline.py:605-607 write samples 1 and 3 only), so its latents at every step are those of the stage-1 call.  With them
+    # cached the stage-2 call need not compute `unc0` at all (its prediction only feeds sample 0's update); `cond0` stays — `cond1`
+    # borrows its attention probabilities — and is fed the cached latents.
+    def put_base(self, key: str, k: int, latents0: torch.Tensor, model_input0: torch.Tensor) -> None:
+        """sample 0 ENTERING step k: its latents (fp32) and the scaled model input the step kernel wrote for it"""
+        self.base.setdefault(key, {})[k] = (latents0.detach().clone(), model_input0.detach().clone())
+
+    def get_base(self, key: str, first: int, n_steps: int):
+        """{k: (latents0, model_input0)} for k = first + 1 .. n_steps if every step is there, else None"""
+        b = self.base.get(key)
+        if b is None or any(k not in b for k in range(first + 1, n_steps + 1)):
+            return None
+        return b
 
 
 class StableDiffusionXLPipelineOutput(SimpleNamespace):
@@ -259,7 +277,7 @@ class LoraMultiConceptPipeline:
                                  styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
                                  lora_mode=lora_mode, controlnet=controlnet if image is not None else None, controlnet_image=image,
                                  controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0), dedup=dedup,
-                                 stage_cache=kwargs.pop("stage_cache", None))[0]
+                                 stage_cache=kwargs.pop("stage_cache", None), drop_unc0=kwargs.pop("drop_unc0", False))[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         images = self._postprocess(lat, output_type)
@@ -299,7 +317,7 @@ class LoraMultiConceptPipeline:
                       concept_lora: bool = True, concept_shard=None,
                       main_adapters: Optional[Sequence[Tuple[str, float]]] = None,
                       concept_adapters: Optional[Sequence[Tuple[str, float]]] = None, concept_adapter_scale: float = 1.0,
-                      stage_cache: Optional[StageCache] = None) -> torch.Tensor:
+                      stage_cache: Optional[StageCache] = None, drop_unc0: bool = False) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -320,6 +338,9 @@ class LoraMultiConceptPipeline:
 
         ``stage_cache`` (:class:`StageCache`, OFF by default): the steps in front of the first fused step of a stage-2 call
         repeat the stage-1 call of the same image; with a cache shared by the two calls the second one starts at step ``fusion_start + 1``.
+        ``drop_unc0=True`` (with a cache that also holds the stage-1 call's trajectory of the base sample): the resumed steps do not compute
+        ``unc0`` — 3 main rows per request instead of 4; the base sample's latents come from the cache at every step (last item:
+        100 + 238 = 338 of the reference's 536 sample-forwards for both stages; bitwise the same latents, tests/test_pipeline_gpu.py).
 
         ``dedup=True`` (OFF by default; SURVEY §7.4, "flag when used"): the reference duplicates the latents (:409) and is called
         with two equal prompts, so until the first fused step the two samples of a request are the same computation twice
@@ -462,12 +483,45 @@ class LoraMultiConceptPipeline:
             raise L.OmgHipError("concept_shard needs the batched step (merged / no LoRA on one shared UNet), a pure-replacement controller and no IdentityNet")
         mshape = tuple(masks_l[0][active[0]].shape) if active else (0, 0)
         D = emb_main.shape[-1]
+        # ---- stage cache: everything that determines the latents entering step fusion_start + 1 of request j; decided in
+        # front of the engine because a resumed call without `unc0` runs a different row plan
+        first = 0
+        cache_keys: List[str] = []
+        cache_hit = None
+        base_traj = None                      # drop_unc0: per step k the (n, C, H, W) latents / model inputs of the base samples
+        if stage_cache is not None and shard is None and S > fusion_start + 1:
+            common = (S, float(guidance_scale), type(self.scheduler).__name__, fusion_start, height, width, tuple(original_size),
+                      tuple(crops_coords_top_left), tuple(target_size), str(dt), tuple(main_adapters), main_scale, lora_mode if main_adapters else None,
+                      id(self.unet), getattr(bank, "version", None) if main_adapters else None,
+                      None if controller is None else (type(controller).__name__, getattr(controller, "is_pure_replacement", False),
+                                                       getattr(controller, "num_self_replace", None)),
+                      None if not use_cn else (id(controlnet), float(controlnet_conditioning_scale)))
+            coef_key = self.scheduler.coef_table(dev)
+            for j in range(n):
+                cn_img = None if not use_cn else (controlnet_image if controlnet_image.shape[0] == 1 else controlnet_image[j: j + 1])
+                cache_keys.append(StageCache.digest(common, coef_key, lats[j], ehs_l[j], text_l[j], cn_img))
+            hit = [stage_cache.get(k) for k in cache_keys]
+            if fuse_possible and all(h is not None for h in hit):
+                first, cache_hit = fusion_start + 1, hit                 # every request resumes: the plain steps are not run at all
+                stage_cache.hits += n
+                if drop_unc0 and batched and not use_idn and (controller is None or getattr(controller, "is_pure_replacement", False)):
+                    bases = [stage_cache.get_base(k, first, S) for k in cache_keys]
+                    if all(b is not None for b in bases):
+                        base_traj = {k: (torch.cat([b[k][0] for b in bases]).to(dev), torch.cat([b[k][1] for b in bases]).to(device=dev, dtype=dt))
+                                     for k in range(first + 1, S + 1)}
+            else:
+                stage_cache.misses += n
+        drop0 = base_traj is not None
+        if drop0:      # the compact-row machinery of the concept shard, on ONE rank: main units of three rows [unc1, cond0, cond1]
+            from . import parallel as _par0
+            shard = _par0.ConceptShard(rank=0, world=1)
+            twin = False
         # ---- persistent engine state (static buffers + captured step graphs), reused across calls of the same shape
         key = (n, S, Cl, Hl, Wl, K, tuple(active), fuse_possible, fusion_start, type(self.scheduler).__name__, float(guidance_scale),
                str(dt), batched, bool(styleL), tuple(main_adapters), tuple(concept_adapters), float(concept_adapter_scale), main_scale,
                tuple(lora_list), mshape, tuple(ehs.shape), id(controller), id(controlnet), id(identitynet),
                float(controlnet_conditioning_scale), float(identitynet_conditioning_scale), twin,
-               (shard.rank, shard.world) if shard is not None else None)
+               (shard.rank, shard.world) if shard is not None else None, drop0)
         eng = self._engines.pop(key, None)
         if eng is not None:
             self._engines[key] = eng                       # most recently used last
@@ -475,7 +529,8 @@ class LoraMultiConceptPipeline:
             eng = SimpleNamespace(graphs={}, warmed=set(), pool=None, coef=None)
             eng.lat = torch.empty((2 * n, Cl, Hl, Wl), dtype=torch.float32, device=dev)
             eng.xin = torch.empty((nb, Cl, Hl, Wl), dtype=dt, device=dev)
-            eng.nout = torch.empty((nb, Cl, Hl, Wl), dtype=torch.float32, device=dev)
+            # drop0: the rows of `unc0` are never written — zeros, so that the step kernel's (discarded) update of the base sample stays finite
+            eng.nout = (torch.zeros if drop0 else torch.empty)((nb, Cl, Hl, Wl), dtype=torch.float32, device=dev)
             eng.step_idx = torch.zeros(1, dtype=torch.int32, device=dev)
             eng.ehs = torch.empty_like(ehs)
             eng.emb_main = torch.empty((S, nm, D), dtype=dt, device=dev)
@@ -510,12 +565,18 @@ class LoraMultiConceptPipeline:
             if shard is not None:      # per regime (plain / fused): this rank's units, its compact local batch and every rank's row map
                 from . import parallel as _par
                 eng.sh = {}
-                for fz in ((False, True) if fuse_possible else (False,)):
-                    per_rank = _par.assign_units(n, Ka, fz, shard.world)
-                    rows = _par.unit_rows(per_rank, n, Ka)
+                for fz in ((True,) if drop0 else (False, True) if fuse_possible else (False,)):
+                    if drop0:      # every unit on this one rank; a main unit is rows 1..3 of the request's block (`unc0` is not computed)
+                        per_rank = [(list(range(n)), [(j, c) for j in range(n) for c in range(Ka)])]
+                        mrows = [4 * j + r for j in range(n) for r in (1, 2, 3)]
+                        rows = [(mrows + [4 * j + 3 for j, _ in per_rank[0][1] for _ in range(2)],
+                                 mrows + [nm + 2 * Ka * j + 2 * c + r for j, c in per_rank[0][1] for r in range(2)])]
+                    else:
+                        per_rank = _par.assign_units(n, Ka, fz, shard.world)
+                        rows = _par.unit_rows(per_rank, n, Ka)
                     mains, concs = per_rank[shard.rank]
                     src, dst = rows[shard.rank]
-                    sh = SimpleNamespace(mains=mains, concs=concs, rows=len(src), n_main=4 * len(mains), counts=[len(r[1]) for r in rows])
+                    sh = SimpleNamespace(mains=mains, concs=concs, rows=len(src), n_main=(3 if drop0 else 4) * len(mains), counts=[len(r[1]) for r in rows])
                     sh.src = torch.tensor(src, dtype=torch.long, device=dev)
                     sh.dsts = [torch.tensor(r[1], dtype=torch.long, device=dev) for r in rows]
                     sh.x = torch.empty((sh.rows, Cl, Hl, Wl), dtype=dt, device=dev)
@@ -555,29 +616,11 @@ class LoraMultiConceptPipeline:
             for c in active:
                 eng.masks[j][c].copy_(masks_l[j][c])
         xin, nout, step_idx, coef = eng.xin, eng.nout, eng.step_idx, eng.coef
-        # ---- stage cache: everything that determines the latents entering step fusion_start + 1 of request j
-        first = 0
-        cache_keys: List[str] = []
-        if stage_cache is not None and shard is None and S > fusion_start + 1:
-            common = (S, float(guidance_scale), type(self.scheduler).__name__, fusion_start, height, width, tuple(original_size),
-                      tuple(crops_coords_top_left), tuple(target_size), str(dt), tuple(main_adapters), main_scale, lora_mode if main_adapters else None,
-                      id(self.unet), getattr(bank, "version", None) if main_adapters else None,
-                      None if controller is None else (type(controller).__name__, getattr(controller, "is_pure_replacement", False),
-                                                       getattr(controller, "num_self_replace", None)),
-                      None if not use_cn else (id(controlnet), float(controlnet_conditioning_scale)))
-            for j in range(n):
-                cn_img = None if not use_cn else (controlnet_image if controlnet_image.shape[0] == 1 else controlnet_image[j: j + 1])
-                cache_keys.append(StageCache.digest(common, coef, lats[j], ehs_l[j], text_l[j], cn_img))
-            hit = [stage_cache.get(k) for k in cache_keys]
-            if fuse_possible and all(h is not None for h in hit):
-                first = fusion_start + 1                                 # every request resumes: the plain steps are not run at all
-                lat.copy_(torch.cat([h.to(dev) for h in hit], dim=0))
-                step_idx.fill_(first)
-                if controller is not None:
-                    controller.cur_step = first                          # the host-side counters the skipped steps would have ticked
-                stage_cache.hits += n
-            else:
-                stage_cache.misses += n
+        if cache_hit is not None:                                        # resume (decided in front of the engine, above)
+            lat.copy_(torch.cat([h.to(dev) for h in cache_hit], dim=0))
+            step_idx.fill_(first)
+            if controller is not None:
+                controller.cur_step = first                              # the host-side counters the skipped steps would have ticked
         cin0 = self.scheduler.cin0(dev) if first == 0 else torch.tensor([self.scheduler.cin[first]], dtype=torch.float32, device=dev)
         for j in range(n):
             ops.scale_model_input(lat[2 * j: 2 * j + 2], cin0, xin[4 * j: 4 * j + 4])
@@ -745,6 +788,8 @@ class LoraMultiConceptPipeline:
             sh = eng.sh[fused]
             kw = dict(main_kw)
             kw["omg_images"] = len(sh.mains)
+            if drop0:
+                kw["omg_main_batch"] = 3                  # [unc1, cond0, cond1]: cond1 borrows Q, K of cond0 = row 1 of the block
             sh.x.copy_(xin[:nm].index_select(0, sh.src))
             if use_cn and sh.n_main:
                 ops.gather_step(sh.cn_emb, step_idx, sh.cn_emb_cur)
@@ -769,6 +814,11 @@ class LoraMultiConceptPipeline:
                     controller.cur_step += 1          # no unit of this step is ours: only the host-side step counter moves
                 shard.exchange(sh.y, sh.counts, sh.dsts, nout)
                 finish(fused)
+                if drop0:      # the base samples were not computed: their latents and next model inputs are the stage-1 call's
+                    bl, bx = base_traj[i + 1]
+                    lat.view(n, 2, Cl, Hl, Wl)[:, 0].copy_(bl)
+                    if i + 1 < S:
+                        xin[:nm].view(n, 4, Cl, Hl, Wl)[:, 2].copy_(bx)
                 return
             run_forward(step_body, fused, tw, (fused,))
 
@@ -810,6 +860,9 @@ class LoraMultiConceptPipeline:
             if cache_keys and first == 0 and i == fusion_start:         # the latents entering the first fused step of a stage-2 call
                 for j, k in enumerate(cache_keys):
                     stage_cache.put(k, lat[2 * j: 2 * j + 2])
+            if cache_keys and first == 0 and i >= fusion_start:         # ... and the base sample's way from there on (drop_unc0)
+                for j, k in enumerate(cache_keys):
+                    stage_cache.put_base(k, i + 1, lat[2 * j: 2 * j + 1], xin[4 * j + 2: 4 * j + 3])
         return lat.clone().view(n, 2, Cl, Hl, Wl)
 
 

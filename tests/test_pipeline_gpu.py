@@ -511,12 +511,12 @@ def test_stage_two_resumes_from_the_stage_one_call_of_the_same_image(dev, use_gr
                     negative_pooled_prompt_embeds=np1.repeat(2, 1), region_prompt_embeds=regions, region_masks=[m1, m2],
                     latents=torch.randn(1, 4, L, L, generator=torch.Generator().manual_seed(seed)))
 
-    def run(reqs, stage, cache=None, dedup=False, guidance=gs):
+    def run(reqs, stage, cache=None, dedup=False, guidance=gs, drop_unc0=False):
         pctl.reset()
         traj = []
         out = pipe.generate_many(reqs, height=H, width=W, num_inference_steps=S, guidance_scale=guidance, cross_attention_kwargs={"scale": 0.8},
                                  controller=pctl, concept_models=concept, stage=stage, lora_list=["c0", "c1"], styleL=False, trajectory=traj,
-                                 fusion_start=fstart, use_graph=use_graph, dedup=dedup, stage_cache=cache)
+                                 fusion_start=fstart, use_graph=use_graph, dedup=dedup, stage_cache=cache, drop_unc0=drop_unc0)
         assert (pctl.cur_step, pctl.cur_att_layer) == (S, 0)
         return out.cpu(), torch.stack([t.cpu() for t in traj])
 
@@ -533,6 +533,18 @@ def test_stage_two_resumes_from_the_stage_one_call_of_the_same_image(dev, use_gr
     assert torch.equal(resumed[:, 0], s1[:, 0]), "the base sample of stage 2 is the stage-1 image (SURVEY §7.4)"
     one_resumed, _ = run(two[1:], 2, cache, dedup=True)                # any subset of cached requests, any batching
     assert torch.equal(one_resumed, full[1:2])
+    # ---- SURVEY 7.4's last item: the base sample is never fused, so its whole trajectory is the stage-1 call's; with it in the cache the
+    # resumed steps run THREE main rows per request ([unc1, cond0, cond1]: `unc0` only ever fed the base sample's update) and still give
+    # the same latents bit for bit — both samples, every step
+    h0 = cache.hits
+    dropped, d_traj = run(two, 2, cache, drop_unc0=True)
+    assert cache.hits == h0 + 2 and torch.equal(dropped, full) and torch.equal(d_traj, full_traj[fstart + 1:])
+    plans = [e.sh[True] for e in pipe._engines.values() if getattr(e, "sh", None) and True in e.sh]
+    assert any(sh.n_main == 3 * len(two) and sh.rows == 3 * len(two) + 4 * len(two) for sh in plans), "three main rows + two concept pairs per request"
+    assert torch.equal(run(two[:1], 2, cache, drop_unc0=True)[0], full[0:1])
+    fresh = StageCache()                                               # a cache without the base trajectory: the plain resume, then the full call
+    run(two, 2, fresh)                                                 # (a stage-2 call fills both the step-16 latents and the base trajectory)
+    assert torch.equal(run(two, 2, fresh, drop_unc0=True)[0], full)
     # ---- misses: nothing is assumed
     for reqs, kw in (([request(3)], {}), ([request(1, eseed=7)], {}), ([request(1)], {"guidance": 5.0})):
         h0 = cache.hits

@@ -124,6 +124,20 @@ if a.what in ("ips", "both"):
                 vae.decode_latents(lat2[j])
             last["lat"], last["i"] = lat2, i
         sec_d = timed(both_dedup, a.steps)
+        drop = {"on": False}
+        def both_min(i):      # + the base sample's stage-1 trajectory from the cache: the resumed steps run without `unc0` (338 forwards)
+            rq = reqs_for(n, i)
+            cache = StageCache()
+            ctl.reset()
+            lat1 = pipe.generate_many([{k: v for k, v in r.items() if k != "region_masks"} for r in rq], stage=1, dedup=True, stage_cache=cache, **kw)
+            for j in range(n):
+                vae.decode_latents(lat1[j])
+            ctl.reset()
+            lat2 = pipe.generate_many(rq, stage=2, stage_cache=cache, drop_unc0=True, **kw)
+            for j in range(n):
+                vae.decode_latents(lat2[j])
+            last["lat_min"], last["i_min"] = lat2, i
+        sec_m = timed(both_min, a.steps)
         ctl.reset()
         want = pipe.generate_many(reqs_for(n, last["i"]), stage=2, **kw)
         print(json.dumps({"measurement": "stage1_plus_stage2_dedup", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec_d, "sec_per_step": sec_d,
@@ -131,6 +145,12 @@ if a.what in ("ips", "both"):
                           "workload": "the same flow with SURVEY 7.4's exact redundancies removed: stage 1 deduplicated ([unc, cond] once per request: 100 "
                                       "sample-forwards), stage 2 resumed at step 16 from the stage-1 latents (StageCache: 34 x 8 = 272); both decodes kept",
                           "steps_timed": a.steps}), flush=True)
+        ctl.reset()
+        want_m = pipe.generate_many(reqs_for(n, last["i_min"]), stage=2, **kw)
+        print(json.dumps({"measurement": "stage1_plus_stage2_minimal", "images_per_step": n, "dtype": a.dtype, "images_per_sec": n / sec_m, "sec_per_step": sec_m,
+                          "sample_forwards_executed": 338, "sample_forwards_reference": 536, "latents_bitwise_equal_to_full_flow": bool(torch.equal(want_m, last["lat_min"])),
+                          "workload": "SURVEY 7.4 in full: stage 1 deduplicated (100), stage 2 resumed at step 16 WITHOUT unc0 — the base sample's latents come from the "
+                                      "stage-1 trajectory in the StageCache (34 x 7 = 238); both decodes kept", "steps_timed": a.steps}), flush=True)
 elif a.what == "config4":
     from omg_amd.controlnet import ControlNetModel
     cn = random_init_(ControlNetModel(UNetConfig.sdxl(), dtype=dt, device=dev), 7)
