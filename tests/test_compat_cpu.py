@@ -94,3 +94,61 @@ def test_the_module_runner_executes_a_script_under_the_aliases(tmp_path, capsys)
     r = subprocess.run([sys.executable, "-m", "omg_amd.run", str(script), "--prompt", "a man"], capture_output=True, text=True, cwd=root, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "omg_amd.compat omg_amd.controller omg_amd.compat ['--prompt', 'a man']" in r.stdout
+
+
+def test_peft_default_active_adapter_bookkeeping(dirs):
+    """``peft_active_adapters``: what PEFT leaves switched on in a pipe when nobody calls ``set_adapters`` — the FIRST adapter loaded into
+    THAT pipe (inference_instantid.py:220-222: one style LoRA per pipe) — per pipe although the weights live in one shared bank; an
+    explicit ``set_adapters`` replaces it."""
+    from omg_amd import compat
+    model, cn_dir, root = dirs
+    compat.clear_component_cache()
+    idn = compat.ControlNetModel.from_pretrained(cn_dir, torch_dtype=torch.float16)
+    pipe = compat.InstantidMultiConceptPipeline.from_pretrained(model, controlnet=idn, torch_dtype=torch.float16, variant="fp16")
+    concept = compat.StableDiffusionXLInstantIDPipeline.from_pretrained(model, controlnet=idn, torch_dtype=torch.float16)
+    assert pipe.peft_active_adapters() == [] == concept.peft_active_adapters()
+    p = hub.write_lora_file(os.path.join(root, "style2", "pytorch_lora_weights.safetensors"), pipe.unet, 13, style="peft", text_encoders=[pipe.text_encoder])
+    pipe.load_lora_weights(os.path.dirname(p), weight_name="pytorch_lora_weights.safetensors", adapter_name="style")
+    assert pipe.peft_active_adapters() == [("style", 1.0)] and concept.peft_active_adapters() == [], "per pipe, not per bank"
+    concept.load_lora_weights(os.path.dirname(p), weight_name="pytorch_lora_weights.safetensors", adapter_name="style")
+    p2 = hub.write_lora_file(os.path.join(root, "loras", "other.safetensors"), pipe.unet, 14)
+    concept.load_lora_weights(p2, adapter_name="other")
+    assert concept.peft_active_adapters() == [("style", 1.0)], "a later load is injected inactive"
+    concept.set_adapters(["other", "style"], adapter_weights=[0.7, 0.5])
+    assert concept.peft_active_adapters() == [("other", 0.7), ("style", 0.5)]
+    assert set(concept.bank.adapters) == {"style", "other"} and concept.bank is pipe._comp.bank
+
+
+def test_mx8_layer_class_map_on_the_module_tree(dirs):
+    """``set_precision_classes``: exactly the named classes get the MX-fp8 flag; everything SURVEY 7.3 item 8 excludes never does; the
+    ControlNet's blocks take the same map; presets are consistent."""
+    from omg_amd import compat
+    from omg_amd.modules import Conv2d, Linear
+    from omg_amd.unet import MX8_CLASSES, MX8_PRESETS, mx8_class_of
+    model, cn_dir, _ = dirs
+    compat.clear_component_cache()
+    cn = compat.ControlNetModel.from_pretrained(cn_dir, torch_dtype=torch.float16)
+    unet = compat.LoraMultiConceptPipeline.from_pretrained(model, controlnet=cn, torch_dtype=torch.float16, variant="fp16").unet
+    assert set(MX8_PRESETS["all"]) == set(MX8_CLASSES) and set(MX8_PRESETS["safe"]) < set(MX8_CLASSES) and MX8_PRESETS["none"] == ()
+    by_cls = {}
+    for name, m in unet.named_modules():
+        if isinstance(m, (Linear, Conv2d)):
+            c = mx8_class_of(name, m)
+            by_cls.setdefault(c, []).append(name)
+    never = by_cls.get(None, [])
+    assert any(n == "conv_in" for n in never) and any(n == "conv_out" for n in never)
+    assert all(not (n.endswith("attn2.to_k") or n.endswith("attn2.to_v")) or mx8_class_of(n, unet.get_submodule(n)) is None for n in sum(by_cls.values(), []))
+    assert any("downsamplers" in n or "upsamplers" in n for n in never) and any("time_emb" in n for n in never)
+    # the tiny test topology has channels that are not multiples of 128: only its eligible Linears / convs can be switched on
+    on = unet.set_precision_classes(MX8_CLASSES)
+    flagged = {n for n, m in unet.named_modules() if isinstance(m, (Linear, Conv2d)) and getattr(m, "mx8", False)}
+    assert on == len(flagged) and flagged <= {n for c, ns in by_cls.items() if c is not None for n in ns}
+    on_safe = unet.set_precision_classes(MX8_PRESETS["safe"])
+    flagged_safe = {n for n, m in unet.named_modules() if isinstance(m, (Linear, Conv2d)) and getattr(m, "mx8", False)}
+    assert on_safe == len(flagged_safe) <= on and all(mx8_class_of(n, unet.get_submodule(n)) in MX8_PRESETS["safe"] for n in flagged_safe)
+    assert unet.set_precision_classes(()) == 0 and unet.linear_precision == "fp16" and unet.conv_precision == "fp16"
+    with pytest.raises(ValueError):
+        unet.set_precision_classes(["no_such_class"])
+    n_cn = cn.set_precision_classes(MX8_CLASSES)
+    assert n_cn == sum(1 for _, m in cn.named_modules() if isinstance(m, (Linear, Conv2d)) and getattr(m, "mx8", False))
+    assert cn.set_precision_classes(()) == 0

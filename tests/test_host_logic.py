@@ -176,3 +176,41 @@ def test_gemm_tile_choice_on_the_workload_shapes():
     assert pick(1048576, 1, 320, 0) == 14            # the same shape as a plain GEMM: 256x128, never 128x320
     # narrow outputs (LoRA down-projection, ControlNet conditioning) never take a 256-wide tile; tiny launches stay on v1
     assert pick(65536, 1, 64, 0) == 14 and pick(2048, 1, 1280, 0) == 1 and pick(77 * 8, 1, 2560, 0) == 1
+
+
+def test_stage_cache_bookkeeping():
+    """StageCache (SURVEY 7.4 between the two calls of an image): keys are content digests — equal tensors give equal keys whatever their
+    identity, any change of content, shape or parameter gives another — entries are copies, the base trajectory is complete only when
+    every step behind the first fused one is there, and eviction drops both."""
+    from omg_amd.pipeline import StageCache
+    a = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    k1 = StageCache.digest((50, 7.5, "DDIM"), a, None)
+    assert k1 == StageCache.digest((50, 7.5, "DDIM"), a.clone(), None)
+    assert k1 != StageCache.digest((50, 7.0, "DDIM"), a, None) != StageCache.digest((50, 7.5, "DDIM"), a + 1, None)
+    assert k1 != StageCache.digest((50, 7.5, "DDIM"), a.reshape(4, 3), None) and k1 != StageCache.digest((50, 7.5, "DDIM"), a.double(), None)
+    c = StageCache(max_entries=2)
+    lat = torch.ones(2, 4, 2, 2)
+    c.put("x", lat)
+    lat.zero_()
+    assert c.get("x").sum() == 2 * 4 * 2 * 2 and c.get("nope") is None, "entries are copies"
+    for k in range(17, 21):
+        c.put_base("x", k, torch.full((1, 4, 2, 2), float(k)), torch.zeros(1, 4, 2, 2, dtype=torch.float16))
+    assert c.get_base("x", 16, 20) is not None and c.get_base("x", 16, 21) is None and c.get_base("x", 15, 20) is None
+    assert float(c.get_base("x", 16, 20)[19][0].mean()) == 19.0
+    c.put("y", lat); c.put("z", lat)                      # third key evicts the oldest, with its trajectory
+    assert c.get("x") is None and c.get_base("x", 16, 20) is None and set(c.entries) == {"y", "z"}
+
+
+def test_controller_source_vector_without_the_base_unconditional_row():
+    """`drop_unc0`: a main block [unc1, cond0, cond1] — every conditional row still borrows Q, K from the FIRST conditional one, which is now
+    row 1 of the block; concept rows batched behind keep their own; a batch of any other size is refused as before."""
+    P = "a man and a woman walking on the street"
+    ctl = pc.AttentionReplace([P, P], 50, {"default_": 1.0}, 0.4, 4, 4, device="cpu")
+    ctl.num_att_layers = 4
+    full = ctl.qk_src_vector(4, "cpu", total_batch=4 * 2 + 4, images=2).tolist()
+    assert full == [0, 1, 2, 2, 4, 5, 6, 6, 8, 9, 10, 11]
+    three = ctl.qk_src_vector(3, "cpu", total_batch=3 * 2 + 4, images=2).tolist()
+    assert three == [0, 1, 1, 3, 4, 4, 6, 7, 8, 9]
+    assert ctl.fused_qk_src(True, 16, 3, device="cpu", total_batch=3, images=1).tolist() == [0, 1, 1]
+    with pytest.raises(ValueError):
+        ctl.fused_qk_src(True, 16, 5, device="cpu")
