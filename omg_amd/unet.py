@@ -284,10 +284,12 @@ def mx8_class_of(name: str, module) -> Optional[str]:
 
 
 def set_mx8_classes(net, classes, select=None) -> int:
-    """Put exactly the layer classes in ``classes`` (names of MX8_CLASSES; empty = everything 16-bit) of ``net`` (UNet or ControlNet) on
+    """Put exactly the layer classes in ``classes`` (names of MX8_CLASSES, or a preset name of MX8_PRESETS; empty = everything 16-bit) of ``net`` (UNet or ControlNet) on
     the block-scaled fp8 MFMA.  ``select(name, cls) -> bool`` (optional) narrows further, e.g. to keep the first / last transformer
     block of a resolution in 16 bits.  Producers follow their consumers (LayerNorm / GroupNorm + SiLU / the GEGLU epilogue write the
     MX-fp8 operand when the layer they feed is fp8).  Returns the number of fp8 layers."""
+    if isinstance(classes, str):                      # a preset name ("all" | "safe" | "none") or one class name
+        classes = MX8_PRESETS.get(classes, (classes,))
     classes = set(classes or ())
     unknown = classes - set(MX8_CLASSES)
     if unknown:

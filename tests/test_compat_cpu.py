@@ -146,6 +146,7 @@ def test_mx8_layer_class_map_on_the_module_tree(dirs):
     on_safe = unet.set_precision_classes(MX8_PRESETS["safe"])
     flagged_safe = {n for n, m in unet.named_modules() if isinstance(m, (Linear, Conv2d)) and getattr(m, "mx8", False)}
     assert on_safe == len(flagged_safe) <= on and all(mx8_class_of(n, unet.get_submodule(n)) in MX8_PRESETS["safe"] for n in flagged_safe)
+    assert unet.set_precision_classes("safe") == on_safe and unet.set_precision_classes("all") == on      # preset names
     assert unet.set_precision_classes(()) == 0 and unet.linear_precision == "fp16" and unet.conv_precision == "fp16"
     with pytest.raises(ValueError):
         unet.set_precision_classes(["no_such_class"])
