@@ -451,14 +451,20 @@ def test_fifty_step_trajectory_error_growth(dev, dtype):
           " ".join(f"{rel[i]:.2e}" for i in (0, 9, 15, 16, 19, 29, 39, 49)))
     # round 4: the same 50 steps by the oracle in the reference's own storage precision (every op's output rounded, oracle/precision.py):
     # how far the REFERENCE's arithmetic drifts from fp32 truth over the loop, and how far the HIP path is from it
+    # (fp16 — the reference's dtype — only: the emulated loop is another ~95 s of host time per dtype; the bf16 curve of round 4 is committed
+    # as profiles/r04_error_growth_bf16.json: bf16 oracle vs fp32 oracle 7.2e-2, HIP vs bf16 oracle 8.7e-2 at the worst step)
     from oracle import precision as oprec
-    octl.reset()
-    rec16 = []
-    with oprec.rounding(dtype):
-        opipe.denoise(main, [conc(0), conc(1)], osch, lat0 * osch.init_noise_sigma, S, gs, 2, masks=masks, fusion_start=fstart, record=rec16)
-    rel_o = [(a - b).abs().max().item() / r for a, b, r in zip(rec16, rec, rms)]
-    rel_h = [(a.float().cpu() - b).abs().max().item() / r for a, b, r in zip(traj, rec16, rms)]
-    print(f"    {name} oracle vs fp32 oracle, worst step {max(rel_o):.2e} (last {rel_o[-1]:.2e});  HIP vs {name} oracle, worst {max(rel_h):.2e} (last {rel_h[-1]:.2e})")
+    rel_o = rel_h = None
+    if dtype == torch.float16:
+        octl.reset()
+        rec16 = []
+        with oprec.rounding(dtype):
+            opipe.denoise(main, [conc(0), conc(1)], osch, lat0 * osch.init_noise_sigma, S, gs, 2, masks=masks, fusion_start=fstart, record=rec16)
+        rel_o = [(a - b).abs().max().item() / r for a, b, r in zip(rec16, rec, rms)]
+        rel_h = [(a.float().cpu() - b).abs().max().item() / r for a, b, r in zip(traj, rec16, rms)]
+        print(f"    {name} oracle vs fp32 oracle, worst step {max(rel_o):.2e} (last {rel_o[-1]:.2e});  HIP vs {name} oracle, worst {max(rel_h):.2e} (last {rel_h[-1]:.2e})")
+        # the HIP path must not be further from exact arithmetic than twice the reference's own storage-precision arithmetic is
+        assert max(rel) < 2.0 * max(rel_o) + 2e-3, (max(rel), max(rel_o))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
