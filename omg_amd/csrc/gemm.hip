@@ -889,6 +889,11 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
 
 #include "gemm_v11.h"      // the 256x256 four-wave tile with the table-driven K loop: schedule 5 = variant 25 (make EXP=1: 35 + SCH too)
 
+int num_cus();
+#ifdef OMG_EXP_KSCHED
+#include "gemm_v12.h"      // next round's experiment (variants 45..48): v11 with the window behind a tile's last barrier used — NOT RUN yet
+#endif
+
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -950,6 +955,15 @@ int launch(const GemmP& p, hipStream_t s) {
             default: return launch_v11_form<T, CONV, 7>(p, s, mrows);
           }
         } else return launch_v11_form<T, CONV, 5>(p, s, mrows);
+      }
+    }
+    // 45..48: gemm_kernel_v12 (gemm_v12.h) — 45 early residual DMA only; 46 persistent (+ early residual); 47 + next-tile prefetch; 48 + counted wait
+    if (v >= 45 && v <= 48 && v6ok) {
+      switch (v) {
+        case 45: return launch_v12_form<T, CONV, 1>(p, s, mrows);
+        case 46: return launch_v12_form<T, CONV, 1 | 2>(p, s, mrows);
+        case 47: return launch_v12_form<T, CONV, 1 | 2 | 4>(p, s, mrows);
+        default: return launch_v12_form<T, CONV, 1 | 2 | 4 | 8>(p, s, mrows);
       }
     }
     if (v == 26 && v6ok) {

@@ -319,8 +319,10 @@ def _experimental_variants():
     try:
         from tests import _codeobj
         from omg_amd import _lib as L_
-        exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in _codeobj.kernels(L_.LIB_PATH))
-        return (26, 35, 36, 40, 41, 42, 43, 44) if exp else ()
+        names = _codeobj.kernels(L_.LIB_PATH)
+        exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in names)
+        v12 = (45, 46, 47, 48) if any("gemm_kernel_v12" in n for n in names) else ()      # next round's experiment (csrc/gemm_v12.h)
+        return ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v12
     except Exception:
         return ()
 
@@ -356,6 +358,50 @@ def test_gemm_variants_are_bitwise_identical(dev, dtype):
             lib.omg_debug_set_gemm_variant(v)
             for k, (o, r) in enumerate(zip(run_all(), base)):
                 assert torch.equal(o, r), f"variant {v} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
+    finally:
+        lib.omg_debug_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("K", [64, 128, 320])
+def test_experimental_persistent_gemm_walks_several_tiles_per_block(dev, K):
+    """EXP builds only (csrc/gemm_v12.h, variants 45..48): the persistent forms with the grid capped at EIGHT blocks (debug bit 0x10000), so
+    that every block walks three or four tiles of a 30-tile problem — first tile, prefetched tiles, last tile; K = 64 / 128 have no full K-loop
+    stage in front of the last one (the prologue's stage-1 branch), adapter -1 groups are skipped by the tile walk.  Bitwise against variant 1."""
+    ev = tuple(v for v in _experimental_variants() if v >= 45)
+    if not ev:
+        pytest.skip("product build: no gemm_kernel_v12")
+    lib = L.lib()
+    dtype = torch.float16
+    M, N = 1100, 1536
+    a = rnd(M, K, dtype=dtype, dev=dev)
+    w = rnd(N, K, dtype=dtype, dev=dev, scale=K ** -0.5)
+    b = rnd(N, dtype=dtype, dev=dev)
+    res = rnd(M, N, dtype=dtype, dev=dev)
+    perm = ops.geglu_row_perm(N).to(dev)
+    wg, bg = w[perm].contiguous(), b[perm].contiguous()
+    a4 = rnd(4 * 512, K, dtype=dtype, dev=dev, seed=5)                        # four groups of 512 rows: 2 x 6 tiles each
+    gb4 = rnd(4, N, dtype=dtype, dev=dev, seed=6)
+    w3 = rnd(2, N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=7)
+    ids = torch.tensor([1, -1, 0, -1], dtype=torch.int32, device=dev)
+    x = rnd(5, 16, 16, 128, dtype=dtype, dev=dev)                             # conv: 1280 rows, 5 x 2 tiles, group bias folded
+    wc = rnd(384, 9 * 128, dtype=dtype, dev=dev, scale=(9 * 128) ** -0.5)
+    bc, gbc = rnd(384, dtype=dtype, dev=dev), rnd(5, 384, dtype=dtype, dev=dev)
+
+    def run_all():
+        o3 = torch.full((4 * 512, N), 7.0, dtype=dtype, device=dev)              # skipped groups keep what was there
+        ops.gemm(a4, w3, bias=b, groups=4, w_group_adapter=ids, out=o3)
+        return [ops.gemm(a, w, bias=b), ops.gemm(a, w, bias=b, residual=res, out_scale=0.5), ops.gemm(a, wg, bias=bg, act=L.ACT_GEGLU),
+                ops.gemm(a4, w, bias=b, group_bias=gb4, groups=4), o3, ops.conv2d(x, wc, 3, bias=bc, group_bias=gbc),
+                ops.conv2d(x, wc, 3, bias=bc, group_bias=gbc, act=L.ACT_SILU)]
+
+    try:
+        lib.omg_debug_set_gemm_variant(1)
+        base = run_all()
+        for v in ev:
+            for cap in (0x10000, 0):
+                lib.omg_debug_set_gemm_variant(v | (cap << 8))
+                for k, (o, r) in enumerate(zip(run_all(), base)):
+                    assert torch.equal(o, r), f"variant {v} cap {cap:#x} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
     finally:
         lib.omg_debug_set_gemm_variant(0)
 

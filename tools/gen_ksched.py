@@ -83,7 +83,43 @@ def emit(i):
     L.append("} while (0)")
     return "\n".join(L)
 
+def emit_last(i):
+    """The LAST stage of a tile (no successor: no fragment reads for a next stage, no DMAs of this tile) with HOOKS for gemm_v12.h: OMG_HEAD(n)
+    behind MFMA n in front of the barrier, OMG_TAIL(n) behind MFMA n after it.  From the barrier on every LDS buffer of the tile is free (all
+    fragment reads of the stage are issued in front of it and waited for by its lgkmcnt(0)): the tail is where the residual tile of THIS tile's
+    epilogue or the first two stages of the NEXT tile can be put in flight under 40 MFMAs."""
+    rd, bar, dma = sched(i)
+    assert i in RING
+    o = order(rd)
+    L = [f"// schedule {i}, last stage of a tile: {2 * bar} head hooks, {64 - 2 * bar} tail hooks"]
+    L.append(f"#define OMG_KS_LAST_{i}() do {{ \\")
+    n = 0
+    for s in range(32):
+        k, q = divmod(s, 8)
+        if s == bar:
+            L.append('  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); \\')
+            n = 0
+        if q == 0:
+            L.append(f"  OMG_XWAIT({k}, {wait_count(rd, k, False)}); \\")
+        hook = "OMG_HEAD" if s < bar else "OMG_TAIL"
+        L.append(f"  OMG_XMM1({k}, {2 * q}); OMG_SB; \\")
+        for kr in o:
+            if rd[kr] == s and s < 8 * kr[0]: L.append(f"  OMG_XRD1({kr[0]}, {kr[1]}, tcur); \\")
+        L.append(f"  {hook}({n}); OMG_SB; \\"); n += 1
+        L.append(f"  OMG_XMM1({k}, {2 * q + 1}); OMG_SB; \\")
+        L.append(f"  {hook}({n}); OMG_SB; \\"); n += 1
+    L.append("} while (0)")
+    return "\n".join(L), 2 * bar, 64 - 2 * bar
+
+
 if __name__ == "__main__":
+    out12 = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "gemm_v12_sched.inc")
+    with open(out12, "w") as f:
+        body, nh, nt = emit_last(5)
+        f.write("// GENERATED by tools/gen_ksched.py — do not edit.  Last-stage body of gemm_kernel_v12 (gemm_v12.h; make EXP=1 only).\n")
+        f.write(f"#define OMG_KS_LAST_HEADS {nh}\n#define OMG_KS_LAST_TAILS {nt}\n")
+        f.write(body + "\n")
+    print("wrote", out12)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "gemm_v11_sched.inc")
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_ksched.py — do not edit.  Stage bodies of gemm_kernel_v11 (gemm_v11.h).\n")
