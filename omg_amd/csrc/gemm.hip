@@ -891,7 +891,7 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
 
 int num_cus();
 #ifdef OMG_EXP_KSCHED
-#include "gemm_v12.h"      // next round's experiment (variants 45..48): v11 with the window behind a tile's last barrier used — NOT RUN yet
+#include "gemm_v12.h"      // tools/exp/ (make EXP=1 adds the include path): next round's experiment, variants 45..48 — NOT RUN yet
 #endif
 
 int num_cus() {
@@ -957,7 +957,7 @@ int launch(const GemmP& p, hipStream_t s) {
         } else return launch_v11_form<T, CONV, 5>(p, s, mrows);
       }
     }
-    // 45..48: gemm_kernel_v12 (gemm_v12.h) — 45 early residual DMA only; 46 persistent (+ early residual); 47 + next-tile prefetch; 48 + counted wait
+    // 45..48: gemm_kernel_v12 (tools/exp/gemm_v12.h) — 45 early residual DMA only; 46 persistent (+ early residual); 47 + next-tile prefetch; 48 + counted wait
     if (v >= 45 && v <= 48 && v6ok) {
       switch (v) {
         case 45: return launch_v12_form<T, CONV, 1>(p, s, mrows);

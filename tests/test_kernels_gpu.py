@@ -321,7 +321,7 @@ def _experimental_variants():
         from omg_amd import _lib as L_
         names = _codeobj.kernels(L_.LIB_PATH)
         exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in names)
-        v12 = (45, 46, 47, 48) if any("gemm_kernel_v12" in n for n in names) else ()      # next round's experiment (csrc/gemm_v12.h)
+        v12 = (45, 46, 47, 48) if any("gemm_kernel_v12" in n for n in names) else ()      # next round's experiment (tools/exp/gemm_v12.h)
         return ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v12
     except Exception:
         return ()
@@ -364,7 +364,7 @@ def test_gemm_variants_are_bitwise_identical(dev, dtype):
 
 @pytest.mark.parametrize("K", [64, 128, 320])
 def test_experimental_persistent_gemm_walks_several_tiles_per_block(dev, K):
-    """EXP builds only (csrc/gemm_v12.h, variants 45..48): the persistent forms with the grid capped at EIGHT blocks (debug bit 0x10000), so
+    """EXP builds only (tools/exp/gemm_v12.h, variants 45..48): the persistent forms with the grid capped at EIGHT blocks (debug bit 0x10000), so
     that every block walks three or four tiles of a 30-tile problem — first tile, prefetched tiles, last tile; K = 64 / 128 have no full K-loop
     stage in front of the last one (the prologue's stage-1 branch), adapter -1 groups are skipped by the tile walk.  Bitwise against variant 1."""
     ev = tuple(v for v in _experimental_variants() if v >= 45)

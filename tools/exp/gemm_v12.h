@@ -1,4 +1,5 @@
-// gemm_v12.h — EXPERIMENT for the next round (built by `make EXP=1` only — variants 45..48; never part of the product library).
+// tools/exp/gemm_v12.h — EXPERIMENT for the next round (built by `make -C omg_amd/csrc EXP=1` only — variants 45..48; never part of the product
+// library, and kept out of omg_amd/csrc until it has run).
 // WRITTEN AT THE END OF ROUND 4 WITH NO GPU TIME LEFT: compiled for gfx950 and inspected (registers, scratch, instruction placement), NOT RUN.
 // tests/test_kernels_gpu.py compares these variants bit for bit with variant 1 as soon as an EXP build meets a GPU; tools/ksched_ab.py times them.
 //

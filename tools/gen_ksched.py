@@ -113,10 +113,10 @@ def emit_last(i):
 
 
 if __name__ == "__main__":
-    out12 = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "gemm_v12_sched.inc")
+    out12 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "gemm_v12_sched.inc")
     with open(out12, "w") as f:
         body, nh, nt = emit_last(5)
-        f.write("// GENERATED by tools/gen_ksched.py — do not edit.  Last-stage body of gemm_kernel_v12 (gemm_v12.h; make EXP=1 only).\n")
+        f.write("// GENERATED by tools/gen_ksched.py — do not edit.  Last-stage body of gemm_kernel_v12 (tools/exp/gemm_v12.h; make EXP=1 only).\n")
         f.write(f"#define OMG_KS_LAST_HEADS {nh}\n#define OMG_KS_LAST_TAILS {nt}\n")
         f.write(body + "\n")
     print("wrote", out12)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# K-loop schedule experiment (omg_amd/csrc/gemm_ksched_exp.h, tools/gen_ksched.py).  In the build container:
+# K-loop schedule experiment (omg_amd/csrc/gemm_v11.h, tools/gen_ksched.py).  In the build container:
 #     make -C omg_amd/csrc EXP=1 DEV=1          # the .so travels to the GPU box with the snapshot (DEV: fp16 kernels only)
 #     gpurun --timeout 600 -- 'bash tools/gpu_exp_ksched.sh'
 #     make -C omg_amd/csrc clean && make -C omg_amd/csrc     # back to the product build afterwards

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5's first GPU call: the experiment prepared (compiled, inspected, never run) at the end of round 4 — gemm_kernel_v12
-# (omg_amd/csrc/gemm_v12.h): v11's ring K loop with the window behind a tile's LAST barrier used for the residual DMA (45), a persistent
+# (tools/exp/gemm_v12.h): v11's ring K loop with the window behind a tile's LAST barrier used for the residual DMA (45), a persistent
 # tile walk (46), the next tile's first two stages issued in front of the epilogue's stores (47) and a counted wait (48).  In the build container:
 #     make -C omg_amd/csrc EXP=1 DEV=1          # the .so travels with the snapshot (DEV: fp16 kernels only)
 #     gpurun --timeout 900 -- 'bash tools/gpu_exp_v12.sh'
