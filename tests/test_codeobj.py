@@ -7,7 +7,7 @@ import pytest
 
 from tests import _codeobj
 
-LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "libomg_hip.so")
+LIB = os.environ.get("OMG_CODEOBJ_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "libomg_hip.so")
 pytestmark = pytest.mark.skipif(not _codeobj.available(LIB), reason="libomg_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')")
 
 
@@ -79,3 +79,35 @@ def test_no_scratch_access_between_the_first_and_the_last_mfma(family):
         assert mf, n
         inside = [ins[i] for i in range(mf[0], mf[-1]) if ins[i].startswith("scratch_")]
         assert not inside, (n, inside[:4])
+
+
+def test_the_experimental_v12_kernels_put_their_loads_in_front_of_the_epilogue_stores(ks):
+    """EXP builds only (tools/exp/gemm_v12.h, never in the product library): what the experiment is about must be true of the code hipcc
+    emitted before anything is timed on it — no scratch in any form; in the prefetching forms (MODE & 4, EF != 2) the 32 LDS-DMA
+    instructions of the next tile's first two stages, and in the early-residual forms (EF == 2) the 32 of the residual tile, sit between
+    the barrier of the tile's last stage and the first store of its epilogue; the counted form (MODE 15, Linear) adds its 16 bias loads there."""
+    v12 = pick(ks, "gemm_kernel_v12")
+    if not v12:
+        pytest.skip("product build: no gemm_kernel_v12 (make -C omg_amd/csrc EXP=1)")
+    for n, k in v12.items():
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (n, k["private_segment_fixed_size"])
+        assert k["agpr_count"] == 256, n
+    dis = _codeobj.disassembly(LIB, "gemm_kernel_v12")
+    checked = 0
+    for n, ins in dis.items():
+        m = re.search(r"Lb([01])ELi(\d)ELi(\d+)EEEv", n)
+        conv, form, mode = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        st = next(i for i, x in enumerate(ins) if x.startswith("buffer_store"))
+        bar = max(i for i in range(st) if ins[i] == "s_barrier")
+        loads = sum(1 for x in ins[bar:st] if x.startswith("buffer_load_dwordx4"))
+        mfma = sum(1 for x in ins[bar:st] if x.startswith("v_mfma"))
+        assert 32 <= mfma <= 40, (n, mfma)                    # the window: the 40 MFMAs behind the barrier (the first stores may overtake the last few)
+        if form == 2:
+            want = 32 if mode & 1 else 0
+        elif mode & 4:
+            want = 32 + (32 if (mode & 8) and not conv else 0)      # counted: + 16 bias and 16 group-bias loads
+        else:
+            want = 0
+        assert (loads >= want) if form == 4 else (loads == want), (n, loads, want)      # form 4 loads its per-row group bias inside the epilogue
+        checked += 1
+    assert checked == len(v12)

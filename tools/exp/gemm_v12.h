@@ -254,6 +254,10 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
     else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fw[ks_][idx_]) : "v"(ad_), "n"(idx_ * 4096));  \
   } while (0)
 #define OMG_XMM1(ks_, n_) acc[(n_) / NT][(n_) % NT] = Vec<T>::mfma32(fw[ks_][(n_) % NT], fa[ks_][(n_) / NT], acc[(n_) / NT][(n_) % NT])
+// the last stage's MFMA, anchored: an empty asm that "modifies" the accumulator keeps the MFMA in its slot.  Inside a K-loop stage the fragment
+// reads of the NEXT stage (asm volatile, overwriting the set an MFMA reads) do that; the last stage has none, and in the persistent form without
+// hooks hipcc moved all 64 MFMAs behind the stage's last wait (seen in the ISA: 16 reads, the barrier, then 64 MFMAs back to back)
+#define OMG_XMML(ks_, n_) do { OMG_XMM1(ks_, n_); asm volatile("" : "+a"(acc[(n_) / NT][(n_) % NT])); } while (0)
 #define OMG_XWAIT(ks_, left_)                                                                              \
   asm volatile("s_waitcnt lgkmcnt(" #left_ ")"                                                             \
                : "+v"(fw[ks_][0]), "+v"(fw[ks_][1]), "+v"(fw[ks_][2]), "+v"(fw[ks_][3]),                   \
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
 #undef OMG_DMAR
 #undef OMG_XWAIT
 #undef OMG_XMM1
+#undef OMG_XMML
 #undef OMG_XRD1
 #undef OMG_SB
 #undef OMG_PREP

@@ -85,7 +85,8 @@ def emit(i):
 
 def emit_last(i):
     """The LAST stage of a tile (no successor: no fragment reads for a next stage, no DMAs of this tile) with HOOKS for gemm_v12.h: OMG_HEAD(n)
-    behind MFMA n in front of the barrier, OMG_TAIL(n) behind MFMA n after it.  From the barrier on every LDS buffer of the tile is free (all
+    behind MFMA n in front of the barrier, OMG_TAIL(n) behind MFMA n after it.  The MFMAs are OMG_XMML (the kernel anchors each one where it
+    is written: with no fragment read of a next stage behind them nothing else keeps them from sinking to the end of the block).  From the barrier on every LDS buffer of the tile is free (all
     fragment reads of the stage are issued in front of it and waited for by its lgkmcnt(0)): the tail is where the residual tile of THIS tile's
     epilogue or the first two stages of the NEXT tile can be put in flight under 40 MFMAs."""
     rd, bar, dma = sched(i)
@@ -102,11 +103,11 @@ def emit_last(i):
         if q == 0:
             L.append(f"  OMG_XWAIT({k}, {wait_count(rd, k, False)}); \\")
         hook = "OMG_HEAD" if s < bar else "OMG_TAIL"
-        L.append(f"  OMG_XMM1({k}, {2 * q}); OMG_SB; \\")
+        L.append(f"  OMG_XMML({k}, {2 * q}); OMG_SB; \\")
         for kr in o:
             if rd[kr] == s and s < 8 * kr[0]: L.append(f"  OMG_XRD1({kr[0]}, {kr[1]}, tcur); \\")
         L.append(f"  {hook}({n}); OMG_SB; \\"); n += 1
-        L.append(f"  OMG_XMM1({k}, {2 * q + 1}); OMG_SB; \\")
+        L.append(f"  OMG_XMML({k}, {2 * q + 1}); OMG_SB; \\")
         L.append(f"  {hook}({n}); OMG_SB; \\"); n += 1
     L.append("} while (0)")
     return "\n".join(L), 2 * bar, 64 - 2 * bar
