@@ -85,7 +85,7 @@ def test_the_experimental_v12_kernels_put_their_loads_in_front_of_the_epilogue_s
     """EXP builds only (tools/exp/gemm_v12.h, never in the product library): what the experiment is about must be true of the code hipcc
     emitted before anything is timed on it — no scratch in any form; in the prefetching forms (MODE & 4, EF != 2) the 32 LDS-DMA
     instructions of the next tile's first two stages, and in the early-residual forms (EF == 2) the 32 of the residual tile, sit between
-    the barrier of the tile's last stage and the first store of its epilogue; the counted form (MODE 15, Linear) adds its 16 bias loads there."""
+    the barrier of the tile's last stage and the first store of its epilogue; the counted form (MODE 15, Linear) adds its 16 bias / group-bias loads there."""
     v12 = pick(ks, "gemm_kernel_v12")
     if not v12:
         pytest.skip("product build: no gemm_kernel_v12 (make -C omg_amd/csrc EXP=1)")
@@ -105,7 +105,7 @@ def test_the_experimental_v12_kernels_put_their_loads_in_front_of_the_epilogue_s
         if form == 2:
             want = 32 if mode & 1 else 0
         elif mode & 4:
-            want = 32 + (32 if (mode & 8) and not conv else 0)      # counted: + 16 bias and 16 group-bias loads
+            want = 32 + (16 if (mode & 8) and not conv else 0)      # counted: + 8 bias and 8 group-bias loads (16 bytes per lane each)
         else:
             want = 0
         assert (loads >= want) if form == 4 else (loads == want), (n, loads, want)      # form 4 loads its per-row group bias inside the epilogue

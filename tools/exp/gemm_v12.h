@@ -13,7 +13,7 @@
 //   MODE bit 2  (with bit 1, EF != 2) the NEXT tile's stages 0 and 1 (32 LDS-DMA instructions per wave) are issued in the same window, i.e. IN
 //               FRONT of the epilogue's first store in program order — round 3's persistent kernel (v9) issued them behind the stores and found
 //               them queued behind those in the CU's memory pipe.  EF == 2 cannot: its residual staging owns four of the five buffers;
-//   MODE bit 3  (with bit 2) the next tile's 16 bias loads are issued in the window as well and the wait in front of the next tile's first
+//   MODE bit 3  (with bit 2) the next tile's 16 bias / group-bias loads are issued in the window as well and the wait in front of the next tile's first
 //               barrier is COUNTED: vmcnt(number of epilogue stores) — the stores of the epilogue (vmcnt counts them on gfx9) need not have
 //               completed, only everything older.  Without bit 3 the wait is vmcnt(0) (correct by construction, pays the store drain).
 // Values: the same loads, the same MFMA order per accumulator, the same epilogue code as v11 — bitwise identical by construction.
