@@ -892,6 +892,7 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
 int num_cus();
 #ifdef OMG_EXP_KSCHED
 #include "gemm_v12.h"      // tools/exp/ (make EXP=1 adds the include path): next round's experiment, variants 45..48 — NOT RUN yet
+#include "gemm_v13.h"      // tools/exp/: the 256 x 320 tile with class-pinned inline-asm MFMAs, variants 27 / 28 — NOT RUN yet
 #endif
 
 int num_cus() {
@@ -957,6 +958,10 @@ int launch(const GemmP& p, hipStream_t s) {
         } else return launch_v11_form<T, CONV, 5>(p, s, mrows);
       }
     }
+    // 27 / 28: gemm_kernel_v13 (tools/exp/gemm_v13.h) — the 256 x 320 tile, register-direct / transposed streaming epilogue; GEGLU stays on 256 x 256
+    if ((v == 27 || v == 28) && v6ok && p.act == OMG_ACT_GEGLU) v = 25;
+    if (v == 27 && v6ok) return launch_v13_form<T, CONV, false>(p, s, mrows);
+    if (v == 28 && v6ok) return launch_v13_form<T, CONV, true>(p, s, mrows);
     // 45..48: gemm_kernel_v12 (tools/exp/gemm_v12.h) — 45 early residual DMA only; 46 persistent (+ early residual); 47 + next-tile prefetch; 48 + counted wait
     if (v >= 45 && v <= 48 && v6ok) {
       switch (v) {

@@ -65,8 +65,9 @@ def kernels(path: str) -> dict:
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
-def disassembly(path: str, needle: str) -> dict:
-    """{kernel symbol: [mnemonic, ...]} for every kernel whose name contains ``needle`` (llvm-objdump -d of the embedded objects)."""
+def disassembly(path: str, needle: str, operands: bool = False) -> dict:
+    """{kernel symbol: [mnemonic, ...]} for every kernel whose name contains ``needle`` (llvm-objdump -d of the embedded objects);
+    ``operands=True`` keeps the whole instruction text ("v_mfma_f32_32x32x16_f16 a[0:15], v[2:5], ...") instead of the mnemonic."""
     out = {}
     with tempfile.TemporaryDirectory() as d:
         for k, blob in enumerate(_code_objects(path)):
@@ -86,5 +87,5 @@ def disassembly(path: str, needle: str) -> dict:
                 elif cur is not None:
                     t = line.strip()
                     if t and not t.startswith(("//", ";")):
-                        out[cur].append(t.split()[0])
+                        out[cur].append(t.split("//")[0].strip() if operands else t.split()[0])
     return out

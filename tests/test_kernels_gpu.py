@@ -322,7 +322,8 @@ def _experimental_variants():
         names = _codeobj.kernels(L_.LIB_PATH)
         exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in names)
         v12 = (45, 46, 47, 48) if any("gemm_kernel_v12" in n for n in names) else ()      # next round's experiment (tools/exp/gemm_v12.h)
-        return ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v12
+        v13 = (27, 28) if any("gemm_kernel_v13" in n for n in names) else ()              # the 256 x 320 tile (tools/exp/gemm_v13.h)
+        return ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v13 + v12
     except Exception:
         return ()
 
@@ -402,6 +403,59 @@ def test_experimental_persistent_gemm_walks_several_tiles_per_block(dev, K):
                 lib.omg_debug_set_gemm_variant(v | (cap << 8))
                 for k, (o, r) in enumerate(zip(run_all(), base)):
                     assert torch.equal(o, r), f"variant {v} cap {cap:#x} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
+    finally:
+        lib.omg_debug_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("K", [64, 128, 192, 640])
+def test_experimental_256x320_tile_is_bitwise_the_other_tiles(dev, K):
+    """EXP builds only (tools/exp/gemm_v13.h, variants 27 = register-direct / 28 = streaming epilogue): the 256 x 320 tile on the widths it is
+    meant for (N = 320 k: whole tiles; both waves' odd 32-column blocks and 128-column groups inside the matrix) and on ragged ones (N = 704:
+    the last tile's columns end inside a 128-column group; N = 192: the odd blocks lie outside the matrix); K = 64 / 128 / 192 have no
+    steady-state stage (one, two, three stages: the peeled copies only); weight slots with a skipped group; per-row group bias + SiLU (form 4),
+    residual (form 5); convolutions with the group bias folded.  Bitwise against variant 1."""
+    ev = tuple(v for v in _experimental_variants() if v in (27, 28))
+    if not ev:
+        pytest.skip("product build: no gemm_kernel_v13")
+    lib = L.lib()
+    dtype = torch.float16
+    M = 1100
+    a = rnd(M, K, dtype=dtype, dev=dev)
+    ws = {N: rnd(N, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=N) for N in (320, 640, 704, 1280, 192)}
+    bs = {N: rnd(N, dtype=dtype, dev=dev, seed=N + 1) for N in ws}
+    res = {N: rnd(M, N, dtype=dtype, dev=dev, seed=N + 2) for N in (640, 704)}
+    a4 = rnd(4 * 512, K, dtype=dtype, dev=dev, seed=5)                        # four groups of 512 rows: 2 x 2 tiles each
+    gb4 = rnd(4, 640, dtype=dtype, dev=dev, seed=6)
+    w3 = rnd(2, 640, K, dtype=dtype, dev=dev, scale=K ** -0.5, seed=7)
+    ids = torch.tensor([1, -1, 0, -1], dtype=torch.int32, device=dev)
+    gb3 = rnd(3, 704, dtype=dtype, dev=dev, seed=8)
+    x = rnd(5, 16, 16, 128, dtype=dtype, dev=dev)                             # conv: 1280 rows, group bias folded (256 rows per sample)
+    x8 = rnd(6, 8, 8, 128, dtype=dtype, dev=dev)                              # 64 rows per sample: per-row group bias
+    wc = {Co: rnd(Co, 9 * 128, dtype=dtype, dev=dev, scale=(9 * 128) ** -0.5, seed=Co) for Co in (320, 640, 192)}
+    bc = {Co: rnd(Co, dtype=dtype, dev=dev, seed=Co + 1) for Co in wc}
+    gbc = {Co: rnd(5, Co, dtype=dtype, dev=dev, seed=Co + 2) for Co in wc}
+    gbc8 = rnd(6, 320, dtype=dtype, dev=dev, seed=9)
+    sc = rnd(5, 16, 16, 320, dtype=dtype, dev=dev, seed=10)                   # a convolution with a residual (shortcut add)
+
+    def run_all():
+        o3 = torch.full((4 * 512, 640), 7.0, dtype=dtype, device=dev)            # skipped groups keep what was there
+        ops.gemm(a4, w3, bias=bs[640], groups=4, w_group_adapter=ids, out=o3)
+        return [ops.gemm(a, ws[N], bias=bs[N]) for N in (320, 640, 704, 1280, 192)] + \
+               [ops.gemm(a, ws[N], bias=bs[N], residual=res[N], out_scale=0.5) for N in (640, 704)] + \
+               [ops.gemm(a4, ws[640], bias=bs[640], group_bias=gb4, groups=4), o3,
+                ops.gemm(a[:600], ws[704], bias=bs[704], group_bias=gb3, groups=3, act=L.ACT_SILU)] + \
+               [ops.conv2d(x, wc[Co], 3, bias=bc[Co], group_bias=gbc[Co]) for Co in (320, 640, 192)] + \
+               [ops.conv2d(x, wc[320], 3, bias=bc[320], group_bias=gbc[320], act=L.ACT_SILU),
+                ops.conv2d(x8, wc[320], 3, bias=bc[320], group_bias=gbc8, act=L.ACT_SILU),
+                ops.conv2d(x, wc[320], 3, bias=bc[320], residual=sc)]
+
+    try:
+        lib.omg_debug_set_gemm_variant(1)
+        base = run_all()
+        for v in ev:
+            lib.omg_debug_set_gemm_variant(v)
+            for k, (o, r) in enumerate(zip(run_all(), base)):
+                assert torch.equal(o, r), f"variant {v} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
     finally:
         lib.omg_debug_set_gemm_variant(0)
 

@@ -1,5 +1,6 @@
 """Within-probe A/B of K-loop schedule variants of the 256x256 four-wave GEMM: interleaved rounds in ONE process (cdna guide §5.4 rule 24),
-median and best TF/s per variant, torch.equal against the shipped schedule.   python tools/ksched_ab.py 25,27,28 [rounds]"""
+median and best TF/s per variant, torch.equal against the first variant listed (0 = the heuristic's choice).
+python tools/ksched_ab.py 25,27,28 [rounds] [k | n320 | n640 | conv | conv320]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,11 +19,18 @@ def t(fn, n=6):
 SEL = sys.argv[3] if len(sys.argv) > 3 else "k"
 shapes = [(65536, 10240, 1280, "geglu"), (65536, 1280, 1280, ""), (65536, 1280, 1280, "res"), (65536, 3840, 1280, ""), (65536, 1280, 5120, "res"), (262144, 640, 640, ""),
           (262144, 5120, 640, "geglu"), (8192, 8192, 8192, "")]
+if SEL == "n320":      # every Linear width of the workload that is a whole number of 320-wide tiles (the 256x320 tile, variants 27 / 28), GEGLU excluded
+    shapes = [(65536, 1280, 1280, "res"), (65536, 1280, 1280, ""), (65536, 3840, 1280, ""), (65536, 1280, 5120, "res"), (262144, 640, 640, "res"), (262144, 640, 640, ""),
+              (262144, 1920, 640, ""), (262144, 640, 2560, "res"), (32768, 1280, 1280, "res"), (32768, 3840, 1280, "")]
 if SEL == "n640":      # the 640-wide Linear layers: 256-wide tiles pad N to 768
     shapes = [(262144, 640, 640, "res"), (262144, 640, 640, ""), (262144, 640, 2560, "res"), (131072, 640, 640, "res"), (262144, 1920, 640, ""), (262144, 5120, 640, "geglu"),
               (131072, 640, 2560, "res"), (65536, 1280, 1280, "res"), (32768, 1280, 1280, "res")]
-if SEL == "conv":      # 3x3 convolutions of the UNet on the 256x256 tile: (B, H, W, Cin, Cout)
-    for B, H, W_, Ci, Co in [(64, 32, 32, 1280, 1280), (64, 64, 64, 640, 640), (64, 32, 32, 2560, 1280), (64, 64, 64, 1280, 640), (16, 128, 128, 640, 640)]:
+if SEL in ("conv", "conv320"):      # 3x3 convolutions of the UNet: (B, H, W, Cin, Cout).  conv: the ones on the 256x256 tile; conv320: the N = 320 / 640
+    # ones the heuristic (variant 0) gives to the 128x320 tile — the 256x320 tile's (27 / 28, tools/exp/gemm_v13.h) first target
+    CONVS = [(64, 32, 32, 1280, 1280), (64, 64, 64, 640, 640), (64, 32, 32, 2560, 1280), (64, 64, 64, 1280, 640), (16, 128, 128, 640, 640)]
+    if SEL == "conv320":
+        CONVS = [(64, 128, 128, 320, 320), (64, 128, 128, 640, 320), (64, 128, 128, 960, 320), (64, 64, 64, 640, 640), (64, 64, 64, 1280, 640), (64, 64, 64, 320, 640)]
+    for B, H, W_, Ci, Co in CONVS:
         x = torch.randn(B, H, W_, Ci, device=dev, dtype=torch.float16)
         w = torch.randn(Co, 9 * Ci, device=dev, dtype=torch.float16) * (9 * Ci) ** -0.5
         b = torch.randn(Co, device=dev, dtype=torch.float16)
