@@ -625,6 +625,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
   }
 }
 
+#ifdef OMG_EXP_KSCHED
+#include "attn_v7.h"       // tools/exp/ (make EXP=1 adds the include path): round 5's experiment — V read row-major through ds_read_b64_tr_b16, NOT RUN yet
+#endif
+
 // V[B, Nkv, heads*64] -> Vt[B, heads, 64, Nkv_pad]; grid (Nkv_pad/64, heads, B)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_v_kernel(const char* V, long ldv, long v_bs, int heads, int Nkv, int Nkv_pad, char* Vt, int mfma_order) {
@@ -759,6 +763,13 @@ int g_attn_variant = 0;      // 0 = heuristic (v3 above 128 keys, v6 up to 128, 
 static int g_attn_qchunk = 512;     // v6: query rows per workgroup strip (tools: bits 8.. of the variant word, in units of 128)
 
 extern "C" void omg_debug_set_attn_variant(int v) { g_attn_variant = v & 0xff; g_attn_qchunk = (v >> 8) ? (v >> 8) * 128 : 512; }
+#ifdef OMG_EXP_KSCHED
+// EXP builds only (tools/exp/attn_v7.h): the row-major V of the NEXT omg_attn_fwd calls while variant 7 is forced — the experiment's side door;
+// the C ABI gets the operand (omg_attn_args) once the kernel has run and won
+static const char* g_attn_v_rowmajor = nullptr;
+static long g_attn_ldv = 0, g_attn_v_bs = 0;
+extern "C" void omg_debug_set_attn_v(const void* V, int64_t ldv, int64_t v_bstride) { g_attn_v_rowmajor = (const char*)V; g_attn_ldv = (long)ldv; g_attn_v_bs = (long)v_bstride; }
+#endif
 
 extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_attn_fwd: null args");
@@ -770,6 +781,14 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   AttnP p = make_params(a);
   dim3 grid((a->Nq + QB - 1) / QB, a->heads, a->B);
   hipStream_t s = (hipStream_t)stream;
+#ifdef OMG_EXP_KSCHED
+  if (g_attn_variant == 7 && g_attn_v_rowmajor != nullptr && g_attn_ldv % 8 == 0) {
+    dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel7<f16>, grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs);
+    else OMG_LAUNCH(attn_fwd_kernel7<bf16>, grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs);
+    return omg_check_launch("attn_fwd_v7");
+  }
+#endif
   if (g_attn_variant == 3 || (g_attn_variant == 0 && a->Nkv > 128)) {   // heuristic: v3 for self-attention, v2 for the 77 / 93 / 16-key cross calls (one or two tiles: latency-bound, v3's 256-row blocks only add to it)
     dim3 grid3((a->Nq + 255) / 256, a->heads, a->B);
     if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel3<f16>, grid3, dim3(256), 0, s, p);

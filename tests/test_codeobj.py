@@ -143,3 +143,19 @@ def test_the_experimental_256x320_tile_keeps_every_accumulator_where_the_source_
         assert ins[mf[-1] + 1] == "s_nop 15" and ins[mf[-1] + 2] == "s_nop 15", (n, ins[mf[-1] + 1:mf[-1] + 4])
         last_write = max(i for i in range(mf[0]) if ins[i].startswith("v_accvgpr_write"))      # the initialisation of the AGPR accumulators
         assert ins[last_write:mf[0]].count("s_nop 15") >= 2, n           # ... is in front of the first fence
+
+
+def test_the_experimental_row_major_v_attention_fits_two_workgroups_per_cu(ks):
+    """EXP builds only (tools/exp/attn_v7.h): attn_fwd_kernel7 = v3 with the V tile staged row-major and transposed on the way out of LDS.
+    It must keep v3's occupancy (two workgroups per CU: <= 256 registers, <= 80 KB of LDS, no scratch) and read every V^T fragment with two
+    ds_read_b64_tr_b16 — 16 per key tile, in each of the three copies of the tile body (first tile, steady state, ragged tail) — where v3 has
+    eight ds_read_b128; the K fragments stay on ds_read_b128."""
+    v7 = pick(ks, "attn_fwd_kernel7")
+    if not v7:
+        pytest.skip("product build: no attn_fwd_kernel7 (make -C omg_amd/csrc EXP=1)")
+    assert len(v7) == 2
+    for n, k in v7.items():
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, n
+        assert k["vgpr_count"] + k.get("agpr_count", 0) <= 256 and k["group_segment_fixed_size"] <= 80 * 1024, n
+    for n, ins in _codeobj.disassembly(LIB, "attn_fwd_kernel7").items():
+        assert ins.count("ds_read_b64_tr_b16") == 48 and ins.count("ds_read_b128") == 24, (n, ins.count("ds_read_b64_tr_b16"), ins.count("ds_read_b128"))

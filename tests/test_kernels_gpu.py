@@ -226,6 +226,42 @@ def test_kv_resident_cross_attention_is_bitwise_the_per_block_kernel(dev, dtype,
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 3, 300, 256), (2, 2, 1024, 1000), (1, 2, 512, 4096), (3, 1, 100, 130)])
+def test_experimental_row_major_v_attention_is_bitwise_the_transposed_v_kernel(dev, dtype, B, heads, Nq, Nkv):
+    """EXP builds only (tools/exp/attn_v7.h, attention variant 7): V read ROW-MAJOR — a view of the fused QKV projection's output, no
+    omg_transpose_v — through ds_read_b64_tr_b16 runs v3's arithmetic in v3's order: plain, with borrowed Q,K, and accumulating; whole tiles,
+    a ragged last tile (1000, 130: the staged rows past Nkv repeat the last key and their probabilities are zeroed), one long row of 64 tiles."""
+    from omg_amd import _lib as L
+    lib = L.lib()
+    if not hasattr(lib, "omg_debug_set_attn_v"):
+        pytest.skip("product build: no attn_fwd_kernel7 (make -C omg_amd/csrc EXP=1)")
+    import ctypes as C_
+    lib.omg_debug_set_attn_v.argtypes = [C_.c_void_p, C_.c_int64, C_.c_int64]
+    lib.omg_debug_set_attn_v.restype = None
+    Cc = heads * 64
+    qkv = rnd(B, max(Nq, Nkv), 3 * Cc, dtype=dtype, dev=dev, scale=1.2)          # V as the product has it: the last third of a fused projection
+    q, k, v = qkv[:, :Nq, :Cc], qkv[:, :Nkv, Cc:2 * Cc], qkv[:, :Nkv, 2 * Cc:]
+    vt = ops.transpose_v(v, heads)
+    src = torch.tensor([max(0, b - 1) for b in range(B)], dtype=torch.int32, device=dev)
+    res = {}
+    try:
+        lib.omg_debug_set_attn_v(v.data_ptr(), v.stride(1), v.stride(0))
+        for var in (3, 7):
+            lib.omg_debug_set_attn_variant(var)
+            a = ops.attention(q, k, vt, heads, 0.125)
+            b_ = ops.attention(q, k, vt, heads, 0.125, qk_src=src)
+            c = a.clone()
+            ops.attention(q, k, vt, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
+            res[var] = (a, b_, c)
+    finally:
+        lib.omg_debug_set_attn_variant(0)
+        lib.omg_debug_set_attn_v(None, 0, 0)
+    for x, y in zip(res[3], res[7]):
+        assert torch.equal(x, y), (x.float() - y.float()).abs().max().item()
+    close(res[7][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_protocol_mode(dev, dtype):
     B, heads, Nq, Nkv = 2, 3, 130, 77
     Cc = heads * 64

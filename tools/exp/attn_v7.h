@@ -1,0 +1,235 @@
+// tools/exp/attn_v7.h — EXPERIMENT for round 5 (built by `make -C omg_amd/csrc EXP=1` only; never part of the product library).
+// WRITTEN IN ROUND 4 WITH NO GPU TIME LEFT: compiled for gfx950 and inspected, NOT RUN.
+//
+// attn_fwd_kernel7 = attn_fwd_kernel3 (attn.hip: 64 query rows per wave, K / V tiles by LDS-DMA, swapped S^T = K Q^T, O^T = V^T P^T) reading V
+// ROW-MAJOR — [key][d], exactly as the QKV projection wrote it — instead of the K-major V^T image omg_transpose_v makes once per attention call
+// (0.9 % of the benchmark step: 3648 launches of 51 us).  The V tile is staged like the K tile (same LDS-DMA pattern, same XOR swizzle) and the
+// P.V MFMA's A operand — 32 d x 16 keys, eight keys per lane — comes out of it by two `ds_read_b64_tr_b16` (gfx950's transposing LDS read) per
+// fragment instead of one ds_read_b128: the same bytes per lane, and the guide prices the transposing read at the plain b64's cost beside
+// MFMAs.  The key order the P registers dictate inside a group of 16 ([0-3, 8-11 | 4-7, 12-15] by lane half) is met by the ADDRESSES the
+// lanes supply, so no permuted image is needed either.
+// What is assumed about the instruction (cdna_hip_programming.md, LDS section + T10; tools/exp/tr16_probe.hip checks exactly this on the
+// part before the kernel is trusted): per group of 16 lanes, lane i supplies the address of 4 consecutive 16-bit elements = row (i >> 2),
+// columns 4 (i & 3) .. + 3 of a 4 x 16 block, and lane c receives column c (4 elements, row order).
+// Ragged last tile: the staged rows past Nkv repeat the last key (as K's do) — finite values, so the probabilities of those keys are set to
+// zero where v3 relied on zero columns of V^T; the ones fragment of the denominator is masked as in v3.  Everything else — loads, MFMA order,
+// softmax arithmetic, stores — is v3's: the result is torch.equal with it (tests/test_kernels_gpu.py).
+// Included inside attn.hip's anonymous namespace.
+template <typename T> struct TrRead;
+template <> struct TrRead<f16> {
+  typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 raw4;
+  static OMG_DEV f16x4 rd(const char* lds) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) raw4*)lds));
+  }
+};
+template <> struct TrRead<bf16> {
+  typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 raw4;
+  static OMG_DEV bf16x4 rd(const char* lds) {
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) raw4*)lds));
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs) {
+  constexpr int QW = 2;                      // 32-row query blocks per wave
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
+  using V8 = typename Vec<T>::v8;
+  using V4 = typename Vec<T>::v4;
+  typedef T T2 __attribute__((ext_vector_type(2)));
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int bq = p.qk_src ? p.qk_src[b] : b;
+  const int q0 = blockIdx.x * (4 * 32 * QW) + w * (32 * QW);
+
+  V8 qf[QW][4];
+  int qrow[QW];
+#pragma unroll
+  for (int qb = 0; qb < QW; ++qb) {
+    int q = q0 + qb * 32 + l31;
+    qrow[qb] = q;
+    if (q >= p.Nq) q = p.Nq - 1;
+    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const V8 raw = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)raw[e] * p.scale_log2e);
+    }
+  }
+
+  // ---- LDS-DMA staging: one instruction = 8 rows x 128 B; wave w moves row blocks w and w + 4 of the K tile and of the V^T tile
+  const int prow = lane >> 3, ppos = lane & 7;
+  const char* kbase = p.K + ((long)bq * p.k_bs + h * 64) * 2;
+  const char* vbase = Vrm + ((long)b * v_bs + h * 64) * 2;        // row-major V: key row stride ldv, the caller's own projection output
+  int srow[2], schunk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    srow[j] = (w + 4 * j) * 8 + prow;
+    schunk[j] = (ppos ^ ((srow[j] >> 1) & 7)) * 16;
+  }
+  // ds_read_b64_tr_b16: every group of 16 lanes fetches a [4 keys][16 d] block — lane i16 of the group supplies the address of the four
+  // consecutive d  4 (i16 & 3) .. + 3  of key (i16 >> 2) of the block — and lane c of the group receives column c: the four keys of d = c.
+  // Group g = lane >> 4 covers d = 16 (g & 1) .. + 15 of the 32-wide d block dt, keys 4 hi + 0..3 (read 0) / 8 + 4 hi + 0..3 (read 1) of a
+  // 16-key group.  vtr[r][dt]: the lane's byte offset inside the tile for (read r, d block dt) of 16-key group 0; group (i, k2) adds
+  // (32 i + 16 k2) * 128 (the swizzle term (key >> 1) & 7 does not change: 16 i + 8 k2 is a multiple of 8).
+  int vtr[2][2];
+  {
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int key = 8 * r + 4 * hi + (i16 >> 2);
+        const int chunk = dt * 4 + 2 * g1 + ((i16 & 3) >> 1);
+        vtr[r][dt] = key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4) + (i16 & 1) * 8;
+      }
+  }
+  auto dma_tile = [&](int kv0, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int key = kv0 + srow[j];
+      if (key > p.Nkv - 1) key = p.Nkv - 1;          // rows past the end repeat the last key; their scores are masked below
+      const char* ks_ = kbase + (long)key * p.ldk * 2 + schunk[j];
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)ks_, (attn_lds_ptr_t)(smem + buf * TILE + (w + 4 * j) * 1024), 16, 0, 0);
+      const char* vs_ = vbase + (long)key * ldv * 2 + schunk[j];      // the same 8 rows x 128 B pattern as K: rows past the end repeat the last key, their P is zeroed
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)vs_, (attn_lds_ptr_t)(smem + (2 + buf) * TILE + (w + 4 * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 o[QW][2], negm[QW];
+  float m_ref[QW], l_run[QW];
+#pragma unroll
+  for (int qb = 0; qb < QW; ++qb) {
+    m_ref[qb] = 0.f; l_run[qb] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; negm[qb][r] = 0.f; }
+  }
+
+  const int ntiles = (p.Nkv + KVB - 1) / KVB;
+  const int nfull = p.Nkv / KVB;             // tiles with 64 real keys
+  dma_tile(0, 0);
+  auto tile_body = [&](const int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int buf = t & 1;
+    const int kv0 = t * KVB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile t has landed
+    __syncthreads();                                     // ... everybody's has, and nobody reads buffer buf^1 any more
+    if (t + 1 < ntiles) dma_tile(kv0 + KVB, buf ^ 1);
+    const char* kt = smem + buf * TILE;
+    const char* vt = smem + (2 + buf) * TILE;
+
+    // ---- S' = K · Q'^T - m_ref for both query blocks: each K fragment feeds two MFMAs
+    f32x16 s[QW][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kc = ks * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + l31;
+        const V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) s[qb][i] = Vec<T>::mfma32(kf, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][i]);
+      }
+    }
+    V8 pf[QW][2][2];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+      float mt = s[qb][0][0];
+#pragma unroll
+      for (int r = 1; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][0][r]), r + 1 < 16 ? s[qb][0][r + 1] : s[qb][0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][1][r]), s[qb][1][r + 1]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      if (t == 0 || __builtin_amdgcn_ballot_w64(mt > ATTN_THR) != 0) {
+        const float d = t == 0 ? mt : fmaxf(mt, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m_ref[qb] += d;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { o[qb][i][r] *= alpha; s[qb][i][r] -= d; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[qb][r] = -m_ref[qb];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float e0 = __builtin_amdgcn_exp2f(s[qb][i][r]);
+          float e1 = __builtin_amdgcn_exp2f(s[qb][i][r + 1]);
+          if constexpr (TAIL) {      // the staged V rows past Nkv are copies of the last key, not zeros: their probabilities are (v3: V^T columns of zeros)
+            const int key = kv0 + i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+            if (key >= p.Nkv) e0 = 0.f;
+            if (key + 1 >= p.Nkv) e1 = 0.f;
+          }
+          const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
+          pf[qb][i][r >> 3][r & 7] = pk[0];
+          pf[qb][i][r >> 3][(r & 7) + 1] = pk[1];
+        }
+    }
+
+    // ---- O^T += V^T · P^T: each V^T fragment feeds two MFMAs; the tile's row sums of P accumulate in `den`, which lives only here
+    // (the score registers are dead by now) — every one of its rows is the sum for the lane's query
+    f32x16 den[QW];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) den[qb][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          // V^T fragment (32 d x 16 keys) out of the ROW-MAJOR tile by two transposing reads: keys 4 hi + 0..3 and 8 + 4 hi + 0..3 of the 16
+          const V4 lo = TrRead<T>::rd(vt + vtr[0][dt] + i * 4096 + k2 * 2048);
+          const V4 hi4 = TrRead<T>::rd(vt + vtr[1][dt] + i * 4096 + k2 * 2048);
+          const V8 vf = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int qb = 0; qb < QW; ++qb) o[qb][dt] = Vec<T>::mfma32(vf, pf[qb][i][k2], o[qb][dt]);
+        }
+        V8 ones;                             // element e of this lane half pairs with key i*32 + k2*16 + (e >> 2)*8 + 4*hi + (e & 3)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (T)((!TAIL || kv0 + i * 32 + k2 * 16 + (e >> 2) * 8 + 4 * hi + (e & 3) < p.Nkv) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) den[qb] = Vec<T>::mfma32(ones, pf[qb][i][k2], den[qb]);
+      }
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) l_run[qb] += den[qb][0];
+  };
+  for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
+  if (nfull < ntiles) tile_body(nfull, std::true_type{});
+
+#pragma unroll
+  for (int qb = 0; qb < QW; ++qb) {
+    const float l_tot = l_run[qb];
+    const float inv = p.out_scale / l_tot;
+    if (qrow[qb] < p.Nq) {
+      char* op = p.O + ((long)b * p.o_bs + (long)qrow[qb] * p.ldo + h * 64) * 2;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * hi;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = o[qb][dt][g * 4 + e] * inv;
+          V4* dst = (V4*)(op + d * 2);
+          if (p.accumulate) {
+            V4 old = *dst;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+          }
+          V4 out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) out[e] = (T)v[e];
+          *dst = out;
+        }
+    }
+  }
+}
+

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round 5, third experiment prepared (compiled, inspected, never run) in round 4 — attn_fwd_kernel7 (tools/exp/attn_v7.h): the self-attention
+# kernel reading V row-major through ds_read_b64_tr_b16, which makes omg_transpose_v (0.9 % of the step) unnecessary.  In the build container
+# (the same EXP build serves gpu_exp_v12.sh / gpu_exp_v13.sh):
+#     make -C omg_amd/csrc EXP=1 DEV=1
+#     gpurun --timeout 600 -- 'bash tools/gpu_exp_attn_v7.sh'
+# 1. the instruction's semantics on the part (tools/exp/tr16_probe.hip: three PASS lines, a few seconds) — the kernel's addressing is built on them;
+# 2. bitwise against v3 (plain, borrowed Q / K, accumulate; whole and ragged tiles);  3. the attention microbenchmark, v3 | v7, with the
+# transpose_v time the new kernel saves printed beside it.
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05
+mkdir -p $O
+hipcc --offload-arch=gfx950 -O2 tools/exp/tr16_probe.hip -o gpurun_out/tr16_probe 2> $O/exp_tr16_probe_build.log && timeout 60 gpurun_out/tr16_probe 2>&1 | tee $O/exp_tr16_probe.log
+grep -c PASS $O/exp_tr16_probe.log | grep -q 3 || { echo "tr16 semantics differ from the guide's statement: see $O/exp_tr16_probe.log"; exit 1; }
+timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "row_major_v_attention" 2>&1 | tail -8 | tee $O/exp_attn_v7_test.log
+grep -q passed $O/exp_attn_v7_test.log || exit 1
+grep -q failed $O/exp_attn_v7_test.log && exit 1
+timeout 300 python tools/attn_bench.py 3 7 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_bench.log
