@@ -14,6 +14,8 @@
 // Ragged last tile: the staged rows past Nkv repeat the last key (as K's do) — finite values, so the probabilities of those keys are set to
 // zero where v3 relied on zero columns of V^T; the ones fragment of the denominator is masked as in v3.  Everything else — loads, MFMA order,
 // softmax arithmetic, stores — is v3's: the result is torch.equal with it (tests/test_kernels_gpu.py).
+// A second question rides on the same kernel (stagger_us, see the kernel's first lines): do the two workgroups of a CU run in lockstep, and does
+// de-phasing them recover the ~3 tiles' worth per workgroup that the 32 x 32 launches (16 key tiles per workgroup) lose against the 64 x 64 ones?
 // Included inside attn.hip's anonymous namespace.
 template <typename T> struct TrRead;
 template <> struct TrRead<f16> {
@@ -30,9 +32,20 @@ template <> struct TrRead<bf16> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int stagger_us) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
+  // tools only (attention variant word 7 | us << 8): half of the launch's first-round workgroups — one of every pair that can share a CU — start
+  // `stagger_us` late.  Two workgroups share a CU and, with equal work, run in lockstep — both in their prologue (Q load, first tile's latency) and both in
+  // their epilogue at the same time; a workgroup takes its successor's place when it ends, so an initial offset persists and one workgroup's
+  // waiting falls under the other's MFMA phase.
+  if (stagger_us > 0) {
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (lin < 512 && (((lin ^ (lin >> 8)) & 1) != 0)) {      // one of (i, i + 1) and one of (i, i + 256): whichever pair the dispatcher puts on a CU
+      const long long t_end = __builtin_amdgcn_s_memrealtime() + (long long)stagger_us * 100;      // 100 MHz counter
+      while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   typedef T T2 __attribute__((ext_vector_type(2)));
