@@ -907,8 +907,8 @@ int num_cus() {
 
 // Tile choice from measured rates (profiles/r01_microbench_*.log): a 256x256 tile wins whenever it can put >= ~120 tiles on the
 // 256 CUs; below that the 256x128 kernel if IT reaches ~120 tiles, else the 128x128 kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
-int choose_variant(int mrows, int groups, int N, bool conv) {
-  if (g_variant != 0) return g_variant;
+int choose_variant(int mrows, int groups, int N, bool conv, double* cost = nullptr) {
+  if (g_variant != 0 && cost == nullptr) return g_variant;
   const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
   const long t256x128 = (long)groups * ((mrows + 255) / 256) * ((N + 127) / 128);
   const long t128x320 = (long)groups * ((mrows + 127) / 128) * ((N + 319) / 320);
@@ -919,6 +919,7 @@ int choose_variant(int mrows, int groups, int N, bool conv) {
   const double c128 = t256x128 >= 120 ? (double)((t256x128 + 255) / 256) * 0.58 * 1.06 : 1e30;
   // 128x320 only for the implicit-GEMM conv (long K): on the Linear layers' K = 640..5120 its per-tile overhead loses
   const double c320 = (conv && N % 320 == 0 && t128x320 >= 120) ? (double)((t128x320 + 255) / 256) * 0.70 : 1e30;
+  if (cost != nullptr) *cost = c320 < c256 && c320 < c128 ? c320 : (c256 <= c128 ? c256 : c128);      // of the choice below, in 256x256-tile rounds (EXP builds: variants 29 / 30)
   if (c320 < c256 && c320 < c128) return 24;
   if (c256 <= c128) return c256 < 1e30 ? 15 : 1;   // 256x256 on four waves (v7); 13 = the eight-wave v6 of the same tile
   return 14;                                       // 256x128 on eight waves (v6)
@@ -929,6 +930,21 @@ int launch(const GemmP& p, hipStream_t s) {
   const int mrows = p.tile_groups > 1 ? p.rows_per_group : p.M;
   if (g_use_glds) {
     int v = choose_variant(mrows, p.tile_groups, p.N, CONV);
+#ifdef OMG_EXP_KSCHED
+    // 29 / 30 (tools/exp/gemm_v13.h): the heuristic with the 256 x 320 tile (its streaming form, 28) as a candidate — 29: where its cost in
+    // rounds x 1.25 is strictly below the heuristic's own choice (it removes padding: N = 640 / 960 / 1920, or replaces the 128 x 320 tile);
+    // 30: wherever N is a multiple of 320 and it fills the chip.  GEGLU stays on 256 x 256.  `OMG_GEMM_VARIANT=29 python bench.py` = the
+    // whole benchmark with it.
+    if (g_variant == 29 || g_variant == 30) {
+      double c_own = 0;
+      v = choose_variant(mrows, p.tile_groups, p.N, CONV, &c_own);
+      const long t320 = (long)p.tile_groups * ((mrows + 255) / 256) * ((p.N + 319) / 320);
+      const double c13 = (double)((t320 + 255) / 256) * 1.25;
+      if (v == 24 && p.act == OMG_ACT_GEGLU) v = 15;
+      if (v == 15) v = 25;                            // what the lines below do for the heuristic (g_variant == 0)
+      if (p.N % 320 == 0 && p.act != OMG_ACT_GEGLU && t320 >= 120 && (g_variant == 30 || c13 < c_own)) v = 28;
+    }
+#endif
     // v6 (interleaved DMA) handles everything except the LoRA second K-segment and > 2 GiB operands
     const long lim = 0x7fff0000L;
     const long a_sz = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 : (long)p.M * p.lda * 2;

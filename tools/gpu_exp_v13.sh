@@ -18,3 +18,11 @@ grep -q failed $O/exp_v13_test.log && exit 1
 timeout 300 python tools/ksched_ab.py 0,27,28 3 conv320 2>&1 | grep -v libdrm | tee $O/exp_v13_ab_conv320.log
 timeout 300 python tools/ksched_ab.py 25,27,28 3 n320 2>&1 | grep -v libdrm | tee $O/exp_v13_ab_n320.log
 timeout 300 python tools/ksched_ab.py 25,27,28 3 conv 2>&1 | grep -v libdrm | tee $O/exp_v13_ab_conv.log
+# 3. if the tile pays: the whole benchmark with the heuristic allowed to pick it (variant 29: where it removes padding or replaces the 128 x 320 tile;
+#    30: wherever N is a multiple of 320), A/B on this box against the product heuristic — two steps each, no CPU leg, per-shape tables kept
+if [ "${BENCH:-1}" = 1 ]; then
+  for V in 0 29 30; do
+    OMG_GEMM_VARIANT=$V timeout 600 python bench.py --steps 2 --warmup 1 --dedup-steps 0 --no-cpu-baseline --by-shape $O/exp_v13_by_shape_v$V.txt > $O/exp_v13_bench_v$V.json 2> $O/exp_v13_bench_v$V.err
+    head -c 400 $O/exp_v13_bench_v$V.json; echo
+  done
+fi
