@@ -1,6 +1,7 @@
 """Kernel-level parity (-m gpu): every C-ABI kernel vs a plain fp32 torch-CPU reference of the
 same op, on the same (dtype-rounded) inputs, at the shapes of SURVEY.md §8(a) plus ragged edges."""
 import math
+import os
 
 import pytest
 import torch
@@ -359,7 +360,9 @@ def _experimental_variants():
         exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in names)
         v12 = (45, 46, 47, 48) if any("gemm_kernel_v12" in n for n in names) else ()      # next round's experiment (tools/exp/gemm_v12.h)
         v13 = (27, 28) if any("gemm_kernel_v13" in n for n in names) else ()              # the 256 x 320 tile (tools/exp/gemm_v13.h)
-        return ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v13 + v12
+        found = ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v13 + v12
+        only = os.environ.get("OMG_EXP_ONLY")                # "27,28": one experiment's variants, so that another's failure is not charged to it
+        return tuple(v for v in found if str(v) in only.split(",")) if only else found
     except Exception:
         return ()
 

@@ -18,3 +18,9 @@ grep -q failed $O/exp_attn_v7_test.log && exit 1
 timeout 300 python tools/attn_bench.py 3 7 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_bench.log
 # the lockstep question (header of tools/exp/attn_v7.h): second workgroup of every CU started 10 / 20 / 40 us late
 timeout 300 python tools/attn_bench.py 7 0xa07 0x1407 0x2807 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_stagger.log
+# 4. the whole benchmark with the self-attention calls on kernel 7 (tools/exp/rowmajor_v_patch.py: the product's Python unchanged, transpose_v skipped);
+#    the baseline line on the same box is gpu_exp_v13.sh's variant-0 run (tools/gpu_round5_first.sh runs both in one call)
+if [ "${BENCH:-1}" = 1 ]; then
+  timeout 600 python tools/exp/run_patched.py bench.py --steps 2 --warmup 1 --dedup-steps 0 --no-cpu-baseline --by-shape $O/exp_attn_v7_by_shape.txt > $O/exp_attn_v7_bench.json 2> $O/exp_attn_v7_bench.err
+  head -c 400 $O/exp_attn_v7_bench.json; echo
+fi

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round 5's FIRST GPU call: the three experiments round 4 prepared without GPU time, on ONE box (boxes of the pool differ by up to 5 %: the A/Bs
+# and the four benchmark lines must share one).  In the build container first:
+#     make -C omg_amd/csrc EXP=1 DEV=1            # fp16 kernels only; the .so travels with the snapshot
+#     gpurun --timeout 2400 -- 'bash tools/gpu_round5_first.sh'
+#     make -C omg_amd/csrc clean && make -C omg_amd/csrc     # back to the product build afterwards
+# Order = cheapest decisive answer first; every numerics block stops ITS experiment on a failure, not the others.
+#   1. tr16 probe + attn_fwd_kernel7 bitwise vs v3 + attention microbenchmark          (~2 min)
+#   2. gemm_kernel_v13 (256 x 320 tile) bitwise + A/B on convolutions and Linears        (~4 min)
+#   3. gemm_kernel_v12 (window behind the last barrier, persistent) bitwise + A/B        (~4 min)
+#   4. whole-benchmark lines, two steps each: product heuristic, v13 where it removes padding (29), v13 wherever N % 320 == 0 (30),
+#      row-major-V attention — skipped for an experiment whose numerics failed                                     (~10 min)
+# Everything lands in gpurun_out/r05/ (copy what is kept into profiles/r05_*).
+cd $GRAFT_REPO_ROOT
+BENCH=0 bash tools/gpu_exp_attn_v7.sh; ATTN_RC=$?
+BENCH=0 bash tools/gpu_exp_v13.sh; V13_RC=$?
+bash tools/gpu_exp_v12.sh; V12_RC=$?
+echo "numerics: attn_v7 rc=$ATTN_RC  gemm_v13 rc=$V13_RC  gemm_v12 rc=$V12_RC"
+O=gpurun_out/r05
+B="--steps 2 --warmup 1 --dedup-steps 0 --no-cpu-baseline"
+timeout 600 python bench.py $B --by-shape $O/first_by_shape_v0.txt > $O/first_bench_v0.json 2> $O/first_bench_v0.err; head -c 300 $O/first_bench_v0.json; echo
+if [ $V13_RC = 0 ]; then
+  for V in 29 30; do
+    OMG_GEMM_VARIANT=$V timeout 600 python bench.py $B --by-shape $O/first_by_shape_v$V.txt > $O/first_bench_v$V.json 2> $O/first_bench_v$V.err; head -c 300 $O/first_bench_v$V.json; echo
+  done
+fi
+if [ $ATTN_RC = 0 ]; then
+  timeout 600 python tools/exp/run_patched.py bench.py $B --by-shape $O/first_by_shape_attn_v7.txt > $O/first_bench_attn_v7.json 2> $O/first_bench_attn_v7.err; head -c 300 $O/first_bench_attn_v7.json; echo
+fi
