@@ -332,6 +332,30 @@ def test_conv_in_out(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 24, 20, 320, 4), (1, 9, 7, 64, 4), (3, 16, 16, 336, 3), (1, 5, 5, 8, 1)])
+def test_experimental_conv_out_with_the_weight_slice_in_registers(dev, dtype, B, H, W, Cin, Cout):
+    """EXP builds only (tools/exp/conv_out_v2.h): the lane's slice of the weights loaded once per wave instead of once per pixel — the same
+    products in the same order: torch.equal with the product kernel (widths with a ragged last iteration, a single-vector width, Cout < 4)."""
+    lib = L.lib()
+    if not hasattr(lib, "omg_debug_set_conv_out_variant"):
+        pytest.skip("product build: no conv_out_kernel2 (make -C omg_amd/csrc EXP=1)")
+    f = rnd(B, H, W, Cin, dtype=dtype, dev=dev)
+    wo = rnd(Cout, 3, 3, Cin, dtype=dtype, dev=dev, scale=(9 * Cin) ** -0.5)
+    bo = rnd(Cout, dtype=dtype, dev=dev)
+    try:
+        base = ops.conv_out(f, wo, bo)
+        lib.omg_debug_set_conv_out_variant(2)
+        new = ops.conv_out(f, wo, bo)
+        new_nobias = ops.conv_out(f, wo, None)
+    finally:
+        lib.omg_debug_set_conv_out_variant(0)
+    assert torch.equal(base, new), (base - new).abs().max().item()
+    assert torch.equal(ops.conv_out(f, wo, None), new_nobias)
+    zref = F.conv2d(f.float().cpu().permute(0, 3, 1, 2), wo.float().cpu().permute(0, 3, 1, 2), bo.float().cpu(), padding=1)
+    torch.testing.assert_close(new.cpu(), zref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_timestep_embedding_and_silu(dev, dtype):
     t = torch.tensor([999.0, 981.0, 1.0, 0.0, 1024.0], device=dev)
     e = ops.timestep_embedding(t, 320, dtype)

@@ -15,6 +15,9 @@ cd $GRAFT_REPO_ROOT
 BENCH=0 bash tools/gpu_exp_attn_v7.sh; ATTN_RC=$?
 BENCH=0 bash tools/gpu_exp_v13.sh; V13_RC=$?
 bash tools/gpu_exp_v12.sh; V12_RC=$?
+# conv_out with the weight slice in registers (tools/exp/conv_out_v2.h; 0.45 % of the step at 14x its memory time): bitwise, then the two kernels timed
+timeout 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "conv_out_with_the_weight_slice" 2>&1 | tail -3 | tee gpurun_out/r05/exp_conv_out_test.log
+timeout 120 python tools/exp/conv_out_bench.py 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_conv_out_bench.log
 echo "numerics: attn_v7 rc=$ATTN_RC  gemm_v13 rc=$V13_RC  gemm_v12 rc=$V12_RC"
 O=gpurun_out/r05
 B="--steps 2 --warmup 1 --dedup-steps 0 --no-cpu-baseline"
