@@ -76,7 +76,11 @@ OMG_DEV float erf_as(float x) {
   const float r = __builtin_fmaf(-poly, e, 1.0f);
   return __builtin_copysignf(r, x);
 }
+#ifdef OMG_EXP_GELU2
+#include "gelu_v2.h"       // tools/exp/ (make GELU2=1 adds the include path): round 5's experiment — gelu_f through ONE transcendental, NOT RUN yet
+#else
 OMG_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+#endif
 
 // ---- MX-fp8 quantisation helpers (gemm_mx8.hip, norm.hip): E8M0 scale of a 32-block and the e4m3 element cast.
 // Scale = the smallest power of two 2^e with amax / 2^e <= 448 (the e4m3 maximum): no element saturates.  Returns e + 127.

@@ -1,0 +1,74 @@
+"""tools/exp/gelu_v2.h (round 5's GELU experiment: `make -C omg_amd/csrc GELU2=1`) on the host: the constants are read out of the header and its
+arithmetic — clamp, eight fp32 FMAs, exp2, max, FMA — is emulated in fp32 (every FMA rounded once) against scipy's erf.  What is asserted is what
+the header claims: no less accurate than the erf_as form (Abramowitz & Stegun 7.1.26) it replaces, q(0) = 0, saturation for large |x|."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+scipy_special = pytest.importorskip("scipy.special")
+
+HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp", "gelu_v2.h")
+f32 = np.float32
+
+
+def _fma(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)      # exact product and sum in fp64, one rounding
+
+
+def _constants():
+    src = open(HDR).read()
+    body = src[src.index("OMG_DEV omg_f32x2 gelu_f2"):]
+    amax = float(re.search(r"fmed3f\(__builtin_fabsf\(x\[0\]\), 0\.0f, ([0-9.e+-]+)f\)", body).group(1))
+    c7 = float(re.search(r"omg_f32x2 p = OMG_S2\(([0-9.e+-]+)f\)", body).group(1))
+    rest = [float(m) for m in re.findall(r"p = __builtin_elementwise_fma\(p, a, OMG_S2\((-?[0-9.e+-]+)f\)\);", body)]
+    assert len(rest) == 6 and re.search(r"fma\(p, a, OMG_S2\(-1\.0f\)\)", body)
+    return amax, [c7] + rest           # highest degree first: c7 .. c1
+
+
+def gelu_v2(x):
+    amax, coef = _constants()
+    x = x.astype(f32)
+    a = np.minimum(np.abs(x), f32(amax))
+    p = np.full_like(a, f32(coef[0]))
+    for c in coef[1:]:
+        p = _fma(p, a, np.full_like(a, f32(c)))
+    h = np.exp2(_fma(p, a, np.full_like(a, f32(-1.0))).astype(np.float64)).astype(f32)
+    r = np.maximum(x, f32(0))
+    return _fma(-a, h, r)
+
+
+def gelu_erf_as(x):
+    x = x.astype(f32)
+    z = (x * f32(0.70710678118654752440)).astype(f32)
+    ax = np.abs(z)
+    one = np.ones_like(ax)
+    t = (1.0 / _fma(f32(0.3275911) * one, ax, one).astype(np.float64)).astype(f32)
+    poly = _fma(f32(1.061405429) * one, t, f32(-1.453152027) * one)
+    for c in (1.421413741, -0.284496736, 0.254829592):
+        poly = _fma(poly, t, f32(c) * one)
+    poly = (poly * t).astype(f32)
+    e = np.exp2(((f32(-1.4426950408889634) * ax).astype(f32) * ax).astype(np.float64)).astype(f32)
+    erf = np.copysign(_fma(-poly, e, one), z)
+    return ((f32(0.5) * x).astype(f32) * (f32(1.0) + erf).astype(f32)).astype(f32)
+
+
+def test_one_transcendental_gelu_is_no_less_accurate_than_the_form_it_replaces():
+    xs = np.concatenate([np.linspace(-12, 12, 1200001), np.random.default_rng(0).normal(0, 2, 400000)]).astype(f32)
+    exact = 0.5 * xs.astype(np.float64) * (1 + scipy_special.erf(xs.astype(np.float64) / np.sqrt(2)))
+    e2 = np.abs(gelu_v2(xs).astype(np.float64) - exact)
+    e1 = np.abs(gelu_erf_as(xs).astype(np.float64) - exact)
+    assert e2.max() < 5e-7, e2.max()                                  # measured 3.9e-7 (erf_as form: 4.7e-7)
+    assert e2.max() <= 1.05 * e1.max(), (e2.max(), e1.max())
+    scale = np.maximum(np.abs(exact), 1e-3)
+    assert (e2 / scale).max() < 2.5e-4 and (e2 / scale).max() <= 1.05 * (e1 / scale).max()      # well inside half an fp16 ulp (4.9e-4) of the product
+
+
+def test_edges():
+    x = np.array([0.0, -0.0, 1e-30, -1e-30, 6.0, -6.0, 100.0, -100.0, 65504.0, -65504.0], dtype=f32)
+    g = gelu_v2(x)
+    assert g[0] == 0 and g[1] == 0 and abs(g[2]) < 1e-29 and abs(g[3]) < 1e-29           # q(0) = 0: h = 1/2 exactly, gelu(0) = 0
+    assert g[6] == f32(100.0) and g[8] == f32(65504.0)                                   # x - 6.01 * 1.5e-9 rounds to x
+    assert -1e-8 < g[7] <= 0 and -1e-8 < g[9] <= 0                                       # -> -0 from below, never positive
+    assert abs(g[4] - 6.0) < 1e-6 and -1e-8 < g[5] < 0

@@ -70,6 +70,28 @@ def test_gemm_geglu(dev, dtype):
     close(out, val * F.gelu(gate), dtype, scale=2.0)
 
 
+@pytest.mark.skipif(os.environ.get("OMG_TEST_GELU_ULP") != "1", reason="round 5 (tools/gpu_exp_gelu2.sh sets OMG_TEST_GELU_ULP=1): written without a GPU, not part of the suite until it has run once")
+def test_geglu_gate_function_is_gelu_to_one_half_precision_ulp(dev):
+    """The gate function of the GEGLU epilogue on its own: value half = 0 * a + 1, so the output IS gelu(gate) rounded to fp16 — compared with the
+    exact erf form in float64 to one fp16 ulp (+ 6e-7 where the result is subnormal-small) over gates from -9 to 9.  Sharp enough to tell a wrong
+    polynomial coefficient from a right one (test_gemm_geglu's 2e-3 is not): the check for `make GELU2=1` (tools/exp/gelu_v2.h) and for the erf_as form alike."""
+    dtype = torch.float16
+    M, K, Cn = 512, 64, 256
+    a = rnd(M, K, dtype=dtype, dev=dev)
+    w_gate = rnd(Cn, K, dtype=dtype, dev=dev, scale=2.5 * K ** -0.5, seed=1)
+    b_gate = rnd(Cn, dtype=dtype, dev=dev, seed=2)
+    w = torch.cat([torch.zeros(Cn, K, dtype=dtype, device=dev), w_gate])
+    b = torch.cat([torch.ones(Cn, dtype=dtype, device=dev), b_gate])
+    perm = ops.geglu_row_perm(2 * Cn).to(dev)
+    out = ops.gemm(a, w[perm].contiguous(), bias=b[perm].contiguous(), act=L.ACT_GEGLU).double().cpu()
+    gate = a.double().cpu() @ w_gate.double().cpu().T + b_gate.double().cpu()
+    ref = 0.5 * gate * (1 + torch.erf(gate / math.sqrt(2)))
+    assert gate.min() < -6 and gate.max() > 6
+    err = (out - ref).abs()
+    tol = ref.abs() * 2.0 ** -10 + 6e-7
+    assert bool((err <= tol).all()), f"worst: {(err / tol).max().item():.2f} x the bound at gate {gate.flatten()[(err / tol).argmax()].item():.3f}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_group_bias_and_strided(dev, dtype):
     B, rows, N, K = 3, 100, 320, 192

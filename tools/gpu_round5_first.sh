@@ -2,6 +2,7 @@
 # Round 5's FIRST GPU call: the three experiments round 4 prepared without GPU time, on ONE box (boxes of the pool differ by up to 5 %: the A/Bs
 # and the four benchmark lines must share one).  In the build container first:
 #     make -C omg_amd/csrc EXP=1 DEV=1            # fp16 kernels only; the .so travels with the snapshot
+#     bash tools/exp/build_alt.sh gelu2 GELU2=1 DEV=1      # the second library of tools/gpu_exp_gelu2.sh
 #     gpurun --timeout 2400 -- 'bash tools/gpu_round5_first.sh'
 #     make -C omg_amd/csrc clean && make -C omg_amd/csrc     # back to the product build afterwards
 # Order = cheapest decisive answer first; every numerics block stops ITS experiment on a failure, not the others.
@@ -18,6 +19,8 @@ bash tools/gpu_exp_v12.sh; V12_RC=$?
 # conv_out with the weight slice in registers (tools/exp/conv_out_v2.h; 0.45 % of the step at 14x its memory time): bitwise, then the two kernels timed
 timeout 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "conv_out_with_the_weight_slice" 2>&1 | tail -3 | tee gpurun_out/r05/exp_conv_out_test.log
 timeout 120 python tools/exp/conv_out_bench.py 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_conv_out_bench.log
+# the one-transcendental GELU (tools/exp/gelu_v2.h), if its second library was built: gate function to one ulp, GEGLU launches timed on both libraries
+[ -f tools/exp/build/gelu2/libomg_hip.so ] && bash tools/gpu_exp_gelu2.sh
 echo "numerics: attn_v7 rc=$ATTN_RC  gemm_v13 rc=$V13_RC  gemm_v12 rc=$V12_RC"
 O=gpurun_out/r05
 B="--steps 2 --warmup 1 --dedup-steps 0 --no-cpu-baseline"

@@ -19,6 +19,8 @@ def t(fn, n=6):
 SEL = sys.argv[3] if len(sys.argv) > 3 else "k"
 shapes = [(65536, 10240, 1280, "geglu"), (65536, 1280, 1280, ""), (65536, 1280, 1280, "res"), (65536, 3840, 1280, ""), (65536, 1280, 5120, "res"), (262144, 640, 640, ""),
           (262144, 5120, 640, "geglu"), (8192, 8192, 8192, "")]
+if SEL == "geglu":     # the GEGLU projections of the workload (tools/gpu_exp_gelu2.sh: one run per library)
+    shapes = [(65536, 10240, 1280, "geglu"), (32768, 10240, 1280, "geglu"), (262144, 5120, 640, "geglu"), (131072, 5120, 640, "geglu")]
 if SEL == "n320":      # every Linear width of the workload that is a whole number of 320-wide tiles (the 256x320 tile, variants 27 / 28), GEGLU excluded
     shapes = [(65536, 1280, 1280, "res"), (65536, 1280, 1280, ""), (65536, 3840, 1280, ""), (65536, 1280, 5120, "res"), (262144, 640, 640, "res"), (262144, 640, 640, ""),
               (262144, 1920, 640, ""), (262144, 640, 2560, "res"), (32768, 1280, 1280, "res"), (32768, 3840, 1280, "")]
