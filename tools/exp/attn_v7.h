@@ -31,7 +31,20 @@ template <> struct TrRead<bf16> {
   }
 };
 
-template <typename T>
+// AQ (attention variant 8 = 7 + this): the FIRST MFMA of every S^T accumulator — the one whose C operand is the splat of the running reference
+// maximum (negm) — written as inline asm in its three-address form (destination != C, early-clobber).  In v3's emitted tile loop hipcc uses that
+// form for the first key block only; for the second it COPIES the 16-register splat (2 x 8 v_mov_b64 per tile and wave) and accumulates in place.
+// The hazard recogniser does not see an asm MFMA; what follows on the same registers are MFMAs of the same opcode accumulating in place (a
+// dependence the matrix pipe handles back to back) and its sources are LDS reads the compiler still waits for.  Same arithmetic, same bits.
+template <typename T> struct MfmaInit;
+template <> struct MfmaInit<f16> {
+  static OMG_DEV void run(f32x16& d, f16x8 a, f16x8 b, const f32x16& c) { asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
+};
+template <> struct MfmaInit<bf16> {
+  static OMG_DEV void run(f32x16& d, bf16x8 a, bf16x8 b, const f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
+};
+
+template <typename T, bool AQ>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int stagger_us) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
@@ -144,7 +157,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
         const int row = i * 32 + l31;
         const V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
-        for (int qb = 0; qb < QW; ++qb) s[qb][i] = Vec<T>::mfma32(kf, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][i]);
+        for (int qb = 0; qb < QW; ++qb) {
+          if (AQ && ks == 0) MfmaInit<T>::run(s[qb][i], kf, qf[qb][ks], negm[qb]);
+          else s[qb][i] = Vec<T>::mfma32(kf, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][i]);
+        }
       }
     }
     V8 pf[QW][2][2];

@@ -16,6 +16,9 @@ from omg_amd import _lib as L
 from omg_amd import ops
 
 
+VARIANT = int(__import__("os").environ.get("OMG_ATTN_EXP_VARIANT", "7"))      # 8 = with the three-address asm first MFMA (tools/exp/attn_v7.h)
+
+
 class RowMajorV:
     """What ``ops.attention`` needs of a V^T tensor (a non-null pointer, the padded key count) around the row-major V view."""
 
@@ -44,7 +47,7 @@ def install() -> None:
             return attention(q, k, vt, heads, scale, **kw)
         v = vt.v
         lib.omg_debug_set_attn_v(v.data_ptr(), v.stride(1), v.stride(0))
-        lib.omg_debug_set_attn_variant(7)
+        lib.omg_debug_set_attn_variant(VARIANT)
         try:
             return attention(q, k, vt, heads, scale, **kw)
         finally:

@@ -15,7 +15,7 @@ grep -c PASS $O/exp_tr16_probe.log | grep -q 3 || { echo "tr16 semantics differ 
 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "row_major_v_attention" 2>&1 | tail -8 | tee $O/exp_attn_v7_test.log
 grep -q passed $O/exp_attn_v7_test.log || exit 1
 grep -q failed $O/exp_attn_v7_test.log && exit 1
-timeout 300 python tools/attn_bench.py 3 7 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_bench.log
+timeout 300 python tools/attn_bench.py 3 7 8 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_bench.log
 # the lockstep question (header of tools/exp/attn_v7.h): second workgroup of every CU started 10 / 20 / 40 us late
 timeout 300 python tools/attn_bench.py 7 0xa07 0x1407 0x2807 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_stagger.log
 # 4. the whole benchmark with the self-attention calls on kernel 7 (tools/exp/rowmajor_v_patch.py: the product's Python unchanged, transpose_v skipped);
