@@ -1,7 +1,7 @@
 #!/bin/bash
 # Measurements beside the headline (one GPU call):   gpurun --timeout 2400 -- 'bash tools/gpu_extras.sh'
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04
+O=gpurun_out/${ROUND:-r05}      # ROUND=r04 reproduces the names of profiles/r04_*
 mkdir -p $O
 : > $O/bench_extras.jsonl
 python tools/bench_extras.py both --steps 1 2>&1 | grep '^{' >> $O/bench_extras.jsonl

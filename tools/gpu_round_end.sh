@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU suite + headline bench (round-end rehearsal):   gpurun --timeout 3600 -- 'bash tools/gpu_round_end.sh'
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04
+O=gpurun_out/${ROUND:-r05}      # ROUND=r04 reproduces the names of profiles/r04_*
 mkdir -p $O
 python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest_gpu.log 2>&1
 tail -22 $O/pytest_gpu.log
