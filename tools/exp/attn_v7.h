@@ -45,7 +45,7 @@ template <> struct MfmaInit<bf16> {
 };
 
 template <typename T, bool AQ>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int stagger_us) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int stagger_us, int xcd_remap) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
   // tools only (attention variant word 7 | us << 8): half of the launch's first-round workgroups — one of every pair that can share a CU — start
@@ -66,9 +66,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // tools only (variant word bit 16): an XCD-aware block order.  Workgroups go to the eight XCDs round-robin by linear id, so the 4 (32 x 32) or 16
+  // (64 x 64) query blocks of one (sample, head) — which stage the same K / V tiles — land on different XCDs and each L2 fetches its own copy
+  // (up to 8 x the K / V bytes over the fabric).  Remapped, the ids an XCD receives enumerate consecutive (query block, head, sample) items.
+  int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  if (xcd_remap) {
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7) == 0) {
+      const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int wi = (lin & 7) * (total >> 3) + (lin >> 3);
+      qblk = wi % (int)gridDim.x;
+      h = (wi / (int)gridDim.x) % (int)gridDim.y;
+      b = wi / (int)(gridDim.x * gridDim.y);
+    }
+  }
   const int bq = p.qk_src ? p.qk_src[b] : b;
-  const int q0 = blockIdx.x * (4 * 32 * QW) + w * (32 * QW);
+  const int q0 = qblk * (4 * 32 * QW) + w * (32 * QW);
 
   V8 qf[QW][4];
   int qrow[QW];
