@@ -974,6 +974,8 @@ int launch(const GemmP& p, hipStream_t s) {
         } else return launch_v11_form<T, CONV, 5>(p, s, mrows);
       }
     }
+    // 31: gemm_kernel_v11, schedule 5 with the short way to the first LDS-DMA (gemm_v11.h, SCH == 10: launch parameters in one batch, adapter id through the scalar cache)
+    if (v == 31 && v6ok) return launch_v11_form<T, CONV, 10>(p, s, mrows);
     // 27 / 28: gemm_kernel_v13 (tools/exp/gemm_v13.h) — the 256 x 320 tile, register-direct / transposed streaming epilogue; GEGLU stays on 256 x 256
     if ((v == 27 || v == 28) && v6ok && p.act == OMG_ACT_GEGLU) v = 25;
     if (v == 27 && v6ok) return launch_v13_form<T, CONV, false>(p, s, mrows);

@@ -33,6 +33,18 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v11(GemmP p) {
   constexpr bool RING = SCH >= 5;
   constexpr int HALF = 32768;
 
+#ifdef OMG_EXP_KSCHED
+  // SCH == 10 (make EXP=1, variant 31; NOT RUN): schedule 5 with a shorter way to the first LDS-DMA.  The emitted prologue of the product kernel
+  // reaches its first DMA after SIX serialised scalar-cache round trips (the launch parameters are fetched field by field, each batch behind the
+  // branch that needs it) and — with per-sample weight slots — one vector-memory round trip for the group's adapter id, all of it per tile.
+  // Here every launch parameter the way to the first DMA needs is requested in ONE batch (the asm only makes them live at this point), and the
+  // adapter id comes through the scalar cache (below).
+  if constexpr (SCH == 10)
+    asm volatile("" ::"s"(p.M), "s"(p.N), "s"(p.K), "s"(p.A), "s"(p.lda), "s"(p.W), "s"(p.ldw), "s"(p.tile_groups), "s"(p.rows_per_group),
+                 "s"(p.group_adapter), "s"(p.w_adapter_stride), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.dbg), "s"(p.bias), "s"(p.group_bias), "s"(p.ldgb));
+  if constexpr (SCH == 10 && CONV)
+    asm volatile("" ::"s"(p.Hin), "s"(p.Win), "s"(p.C1), "s"(p.C2), "s"(p.Hout), "s"(p.Wout), "s"(p.ksize), "s"(p.stride), "s"(p.upsample), "s"(p.X2));
+#endif
   const bool ts_on = (p.dbg & 16) && blockIdx.x < 8192 && threadIdx.x == 0;      // tools/gemm_timeline.py: per-block time stamps
   long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (p.dbg & 16) ts0 = __builtin_amdgcn_s_memrealtime();
@@ -67,6 +79,11 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v11(GemmP p) {
   const int m0 = m_base + tm * BM_;
   const int n0 = tn * BN_;
   int adapter = 0;
+#ifdef OMG_EXP_KSCHED
+  if constexpr (SCH == 10) {      // the adapter id of the tile's group through the scalar cache (the table is written before the launch, never by it)
+    if (p.group_adapter != nullptr) adapter = *(const __attribute__((address_space(4))) int*)(p.group_adapter + grp);
+  } else
+#endif
   if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
   if (p.w_adapter_stride != 0 && adapter < 0) return;
   const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
@@ -198,7 +215,8 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v11(GemmP p) {
   do {                                                                                                     \
     if constexpr (SCH == 0) { what_(0); } else if constexpr (SCH == 1) { what_(1); } else if constexpr (SCH == 2) { what_(2); } \
     else if constexpr (SCH == 3) { what_(3); } else if constexpr (SCH == 4) { what_(4); } else if constexpr (SCH == 5) { what_(5); } \
-    else if constexpr (SCH == 6) { what_(6); } else if constexpr (SCH == 7) { what_(7); } else if constexpr (SCH == 8) { what_(8); } else { what_(9); } \
+    else if constexpr (SCH == 6) { what_(6); } else if constexpr (SCH == 7) { what_(7); } else if constexpr (SCH == 8) { what_(8); } \
+    else if constexpr (SCH == 10) { what_(5); } else { what_(9); } \
   } while (0)
 #else
   static_assert(SCH == 5, "the product build carries schedule 5 only (make EXP=1 for the others)");

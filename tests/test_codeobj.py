@@ -34,11 +34,11 @@ def test_the_16_bit_gemm_instances_of_the_256_tile_use_no_scratch_at_all(ks):
     gb / SiLU (4) — free of spills and scratch; the product build carries schedule 5 only."""
     seen = {}
     for n, k in pick(ks, "gemm_kernel_v11").items():
-        m = re.search(r"Lb([01])ELi(\d)ELi(\d)EEEv", n)
+        m = re.search(r"Lb([01])ELi(\d)ELi(\d+)EEEv", n)
         conv, form, sch = int(m.group(1)), int(m.group(2)), int(m.group(3))
         seen.setdefault((form, sch), []).append(conv)
         assert k["agpr_count"] == 256 and k["max_flat_workgroup_size"] == 256, n        # 256 accumulators in AGPRs, one wave per SIMD
-        if sch == 5:                                                                        # the product schedule; EXP builds: schedule 8's GEGLU form parks two registers
+        if sch in (5, 10):                                                                  # the product schedule (10 = EXP builds: the same with the short prologue); EXP builds: schedule 8's GEGLU form parks two registers
             assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0, (n, k["private_segment_fixed_size"])
         assert k["private_segment_fixed_size"] <= 16, (n, k["private_segment_fixed_size"])
         assert k["group_segment_fixed_size"] == 0, n                                        # dynamic LDS only: 5 x 32 KB
@@ -161,3 +161,23 @@ def test_the_experimental_row_major_v_attention_fits_two_workgroups_per_cu(ks):
         assert ins.count("ds_read_b64_tr_b16") == 48 and ins.count("ds_read_b128") == 24, (n, ins.count("ds_read_b64_tr_b16"), ins.count("ds_read_b128"))
         if "Lb1EEEv" in n:                                # the asm form: no 16-register copies of the reference-maximum splat in front of the tile's MFMAs
             assert ins.count("v_mov_b64_e32") <= 64 and ins.count("v_mov_b32_e32") <= 200, (n, ins.count("v_mov_b64_e32"), ins.count("v_mov_b32_e32"))
+
+
+def test_the_short_prologue_reaches_its_first_lds_dma_behind_fewer_round_trips(ks):
+    """EXP builds only (gemm_v11.h, SCH == 10 = variant 31).  The product kernel of the 256 x 256 tile fetches its launch parameters field by field —
+    five or six `s_waitcnt` in front of the first LDS-DMA, one of them on the VECTOR-memory load of the group's adapter id — once per tile.  The experiment
+    requests them in one batch and reads the adapter id through the scalar cache: at most four waits (Linear: three), no vector load in front of the
+    first DMA.  Product builds: those waits are asserted instead, so that the finding stays true of what is shipped until the experiment lands."""
+    dis = _codeobj.disassembly(LIB, "gemm_kernel_v11", operands=True)
+
+    def way_to_first_dma(ins):
+        first = next(i for i, x in enumerate(ins) if x.startswith("buffer_load_dwordx4") and x.endswith("lds"))
+        head = ins[:first]
+        return sum(1 for x in head if x.startswith("s_waitcnt")), sum(1 for x in head if x.startswith(("global_load", "flat_load")))
+
+    short = {n: way_to_first_dma(i) for n, i in dis.items() if "ELi10EEEv" in n}
+    prod = {n: way_to_first_dma(i) for n, i in dis.items() if "ELi5EEEv" in n}
+    assert prod and all(w >= 5 and v == 1 for w, v in prod.values()), prod
+    if not short:
+        pytest.skip("product build: no SCH == 10 instance of gemm_kernel_v11 (make -C omg_amd/csrc EXP=1)")
+    assert all(w <= 4 and v == 0 for w, v in short.values()), short

@@ -16,6 +16,14 @@ cd $GRAFT_REPO_ROOT
 BENCH=0 bash tools/gpu_exp_attn_v7.sh; ATTN_RC=$?
 BENCH=0 bash tools/gpu_exp_v13.sh; V13_RC=$?
 bash tools/gpu_exp_v12.sh; V12_RC=$?
+# the short way to the first LDS-DMA (gemm_v11.h SCH == 10, variant 31: launch parameters in one batch, adapter id through the scalar cache — the
+# product prologue makes six serialised scalar-cache round trips and, with weight slots, a vector-memory one, per tile): bitwise, then A/B on the
+# transformer Linears as the fused steps launch them (64 weight slots) and on the plain shapes
+OMG_EXP_ONLY=31 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "(variants_are_bitwise and dtype0) or 256x320_tile" 2>&1 | tail -3 | tee gpurun_out/r05/exp_v31_test.log
+if grep -q passed gpurun_out/r05/exp_v31_test.log && ! grep -q failed gpurun_out/r05/exp_v31_test.log; then
+  timeout 300 python tools/ksched_ab.py 25,31 3 slots 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_v31_ab_slots.log
+  timeout 300 python tools/ksched_ab.py 25,31 3 k 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_v31_ab_k.log
+fi
 # conv_out with the weight slice in registers (tools/exp/conv_out_v2.h; 0.45 % of the step at 14x its memory time): bitwise, then the two kernels timed
 timeout 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "conv_out_with_the_weight_slice" 2>&1 | tail -3 | tee gpurun_out/r05/exp_conv_out_test.log
 timeout 120 python tools/exp/conv_out_bench.py 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_conv_out_bench.log

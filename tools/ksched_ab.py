@@ -1,6 +1,6 @@
 """Within-probe A/B of K-loop schedule variants of the 256x256 four-wave GEMM: interleaved rounds in ONE process (cdna guide §5.4 rule 24),
 median and best TF/s per variant, torch.equal against the first variant listed (0 = the heuristic's choice).
-python tools/ksched_ab.py 25,27,28 [rounds] [k | n320 | n640 | conv | conv320]"""
+python tools/ksched_ab.py 25,27,28 [rounds] [k | n320 | n640 | slots | geglu | conv | conv320]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -50,8 +50,30 @@ if SEL in ("conv", "conv320"):      # 3x3 convolutions of the UNet: (B, H, W, Ci
         med = lambda a: sorted(a)[len(a) // 2]
         print(f"conv {B}x{H}x{W_} {Ci}->{Co} " + "  ".join(f"v{v}: med {fl/med(ts[v]):6.0f} best {fl/min(ts[v]):6.0f} eq={int(torch.equal(outs[v], outs[VARS[0]]))}" for v in VARS), flush=True)
     sys.exit(0)
+if SEL == "slots":     # the transformer Linears as the fused steps launch them: 64 samples, each with its own weight slot (merged LoRA), adapter ids on the device
+    shapes = [(65536, 3840, 1280, "slots"), (65536, 1280, 1280, "slots+res"), (65536, 1280, 5120, "slots+res"), (65536, 10240, 1280, "slots+geglu"), (262144, 640, 640, "slots+res")]
 for M, N, K, kind in shapes:
     x = torch.randn(M, K, device=dev, dtype=torch.float16)
+    if kind.startswith("slots"):
+        w3 = torch.randn(3, N, K, device=dev, dtype=torch.float16) * K ** -0.5
+        ids = torch.tensor([(g * 7) % 3 for g in range(64)], dtype=torch.int32, device=dev)
+        b = torch.randn(N, device=dev, dtype=torch.float16)
+        res = torch.randn(M, N, device=dev, dtype=torch.float16) if "res" in kind else None
+        geglu = "geglu" in kind
+        out = torch.empty(M, N // 2 if geglu else N, device=dev, dtype=torch.float16)
+        f = lambda: ops.gemm(x, w3, bias=b, residual=res, act=L.ACT_GEGLU if geglu else 0, groups=64, w_group_adapter=ids, out=out)
+        ts, outs = {v: [] for v in VARS}, {}
+        for r in range(R):
+            for v in VARS:
+                lib.omg_debug_set_gemm_variant(v)
+                ts[v].append(t(f))
+                if r == 0:
+                    outs[v] = out.clone()
+        lib.omg_debug_set_gemm_variant(0)
+        fl = 2 * M * N * K / 1e9
+        med = lambda a: sorted(a)[len(a) // 2]
+        print(f"{M}x{N}x{K} {kind:12s} " + "  ".join(f"v{v}: med {fl/med(ts[v]):6.0f} best {fl/min(ts[v]):6.0f} eq={int(torch.equal(outs[v], outs[VARS[0]]))}" for v in VARS), flush=True)
+        continue
     w = torch.randn(N, K, device=dev, dtype=torch.float16) * K ** -0.5
     b = torch.randn(N, device=dev, dtype=torch.float16)
     res = torch.randn(M, N, device=dev, dtype=torch.float16) if kind == "res" else None
