@@ -782,15 +782,17 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   dim3 grid((a->Nq + QB - 1) / QB, a->heads, a->B);
   hipStream_t s = (hipStream_t)stream;
 #ifdef OMG_EXP_KSCHED
-  if ((g_attn_variant == 7 || g_attn_variant == 8) && g_attn_v_rowmajor != nullptr && g_attn_ldv % 8 == 0) {      // 8 = 7 + the asm three-address first MFMA
+  if (g_attn_variant >= 7 && g_attn_variant <= 9 && g_attn_v_rowmajor != nullptr && g_attn_ldv % 8 == 0) {      // 8 = 7 + the asm three-address first MFMA and all Q loads up front; 9 = 8 + the knobs
     dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);
-    const int hi_bits = g_attn_qchunk == 512 ? 0 : g_attn_qchunk / 128;         // bits 8.. of the variant word (tools/exp/attn_v7.h):
+    const int hi_bits = g_attn_qchunk == 512 ? 0 : g_attn_qchunk / 128;         // bits 8.. of the variant word (tools/exp/attn_v7.h, variant 9 only):
     const int stagger_us = hi_bits & 0xff, xcd_remap = (hi_bits >> 8) & 1;       // 8..15 the start delay in us, 16 the XCD-aware block order
-    if (g_attn_variant == 8) {
-      if (a->dtype == OMG_F16) OMG_LAUNCH((attn_fwd_kernel7<f16, true>), grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs, stagger_us, xcd_remap);
-      else OMG_LAUNCH((attn_fwd_kernel7<bf16, true>), grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs, stagger_us, xcd_remap);
-    } else if (a->dtype == OMG_F16) OMG_LAUNCH((attn_fwd_kernel7<f16, false>), grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs, stagger_us, xcd_remap);
-    else OMG_LAUNCH((attn_fwd_kernel7<bf16, false>), grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs, stagger_us, xcd_remap);
+#define OMG_L7(T_, AQ_, KN_) OMG_LAUNCH((attn_fwd_kernel7<T_, AQ_, KN_>), grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs, stagger_us, xcd_remap)
+    if (a->dtype == OMG_F16) {
+      if (g_attn_variant == 7) OMG_L7(f16, false, false); else if (g_attn_variant == 8) OMG_L7(f16, true, false); else OMG_L7(f16, true, true);
+    } else {
+      if (g_attn_variant == 7) OMG_L7(bf16, false, false); else if (g_attn_variant == 8) OMG_L7(bf16, true, false); else OMG_L7(bf16, true, true);
+    }
+#undef OMG_L7
     return omg_check_launch("attn_fwd_v7");
   }
 #endif

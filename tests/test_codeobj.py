@@ -153,13 +153,13 @@ def test_the_experimental_row_major_v_attention_fits_two_workgroups_per_cu(ks):
     v7 = pick(ks, "attn_fwd_kernel7")
     if not v7:
         pytest.skip("product build: no attn_fwd_kernel7 (make -C omg_amd/csrc EXP=1)")
-    assert len(v7) == 4                                  # f16 / bf16 x (builtin | three-address asm) first MFMA of the S^T accumulators
+    assert len(v7) == 6                                  # f16 / bf16 x (7 | 8 = three-address asm first MFMA, Q loads up front | 9 = 8 + tools-only knobs)
     for n, k in v7.items():
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, n
         assert k["vgpr_count"] + k.get("agpr_count", 0) <= 256 and k["group_segment_fixed_size"] <= 80 * 1024, n
     for n, ins in _codeobj.disassembly(LIB, "attn_fwd_kernel7").items():
         assert ins.count("ds_read_b64_tr_b16") == 48 and ins.count("ds_read_b128") == 24, (n, ins.count("ds_read_b64_tr_b16"), ins.count("ds_read_b128"))
-        if "Lb1EEEv" in n:                                # the asm form: no 16-register copies of the reference-maximum splat in front of the tile's MFMAs
+        if "Lb1ELb" in n:                                # the asm form: no 16-register copies of the reference-maximum splat in front of the tile's MFMAs
             assert ins.count("v_mov_b64_e32") <= 64 and ins.count("v_mov_b32_e32") <= 200, (n, ins.count("v_mov_b64_e32"), ins.count("v_mov_b32_e32"))
 
 

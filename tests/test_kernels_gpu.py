@@ -269,7 +269,7 @@ def test_experimental_row_major_v_attention_is_bitwise_the_transposed_v_kernel(d
     res = {}
     try:
         lib.omg_debug_set_attn_v(v.data_ptr(), v.stride(1), v.stride(0))
-        for var in (3, 7, 8):                                # 8 = 7 with the first MFMA of every S^T accumulator as a three-address inline asm
+        for var in (3, 7, 8, 9):                             # 8 = 7 with the first MFMA of every S^T accumulator as a three-address inline asm and every Q load up front; 9 = 8 + the tools' knobs (off here)
             lib.omg_debug_set_attn_variant(var)
             a = ops.attention(q, k, vt, heads, 0.125)
             b_ = ops.attention(q, k, vt, heads, 0.125, qk_src=src)
@@ -279,7 +279,7 @@ def test_experimental_row_major_v_attention_is_bitwise_the_transposed_v_kernel(d
     finally:
         lib.omg_debug_set_attn_variant(0)
         lib.omg_debug_set_attn_v(None, 0, 0)
-    for var in (7, 8):
+    for var in (7, 8, 9):
         for x, y in zip(res[3], res[var]):
             assert torch.equal(x, y), (var, (x.float() - y.float()).abs().max().item())
     close(res[7][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)

@@ -20,7 +20,7 @@ def timeit(fn, iters=30, warm=10):
 
 dev, dt = torch.device("cuda:0"), torch.float16
 lib = L.lib()
-VARS = tuple(int(a, 0) for a in sys.argv[1:]) or (0,)      # EXP builds: 7 | us << 8 = variant 7 with half of the first-round workgroups started `us` late; | 1 << 16 = XCD-aware block order
+VARS = tuple(int(a, 0) for a in sys.argv[1:]) or (0,)      # EXP builds: 9 | us << 8 = variant 9 (= 8 + knobs) with half of the first-round workgroups started `us` late; | 1 << 16 = XCD-aware block order
 print("# variants", VARS, "(0 = the heuristic: v3 above 128 keys, v2 below; 2 = v2; 3 = v3; 7 = EXP builds: v3 reading V row-major; 8 = 7 + three-address asm first MFMA) — OMG_HIP_LIB=<other build> runs the same table on another library for A/B")
 print("# (B, heads, Nq, Nkv): TF/s per variant; max |last - first variant|")
 for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20, 1024, 77), (64, 10, 4096, 77), (32, 10, 4096, 4096), (64, 20, 1024, 16)]:
@@ -33,7 +33,7 @@ for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20,
         import ctypes
         lib.omg_debug_set_attn_v.argtypes, lib.omg_debug_set_attn_v.restype = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64], None
         lib.omg_debug_set_attn_v(v.data_ptr(), v.stride(1), v.stride(0))
-    t_tr = timeit(lambda: ops.transpose_v(v, heads, out=vt)) if any(v & 0xff in (7, 8) for v in VARS) and Nkv > 128 else None
+    t_tr = timeit(lambda: ops.transpose_v(v, heads, out=vt)) if any(v & 0xff in (7, 8, 9) for v in VARS) and Nkv > 128 else None
     out = torch.empty(B, Nq, C, device=dev, dtype=dt)
     fl = 4.0 * B * heads * Nq * Nkv * 64
     res, outs = [], []

@@ -44,15 +44,17 @@ template <> struct MfmaInit<bf16> {
   static OMG_DEV void run(f32x16& d, bf16x8 a, bf16x8 b, const f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
 };
 
-template <typename T, bool AQ>
+// KNOBS (attention variant 9 = 8 + the two tools-only knobs below; 7 and 8 carry neither: reading their two arguments and the grid size costs four
+// more scalar round trips in front of the first Q load)
+template <typename T, bool AQ, bool KNOBS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int stagger_us, int xcd_remap) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
-  // tools only (attention variant word 7 | us << 8): half of the launch's first-round workgroups — one of every pair that can share a CU — start
+  // tools only (attention variant word 9 | us << 8): half of the launch's first-round workgroups — one of every pair that can share a CU — start
   // `stagger_us` late.  Two workgroups share a CU and, with equal work, run in lockstep — both in their prologue (Q load, first tile's latency) and both in
   // their epilogue at the same time; a workgroup takes its successor's place when it ends, so an initial offset persists and one workgroup's
   // waiting falls under the other's MFMA phase.
-  if (stagger_us > 0) {
+  if (KNOBS && stagger_us > 0) {
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     if (lin < 512 && (((lin ^ (lin >> 8)) & 1) != 0)) {      // one of (i, i + 1) and one of (i, i + 256): whichever pair the dispatcher puts on a CU
       const long long t_end = __builtin_amdgcn_s_memrealtime() + (long long)stagger_us * 100;      // 100 MHz counter
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
   // (64 x 64) query blocks of one (sample, head) — which stage the same K / V tiles — land on different XCDs and each L2 fetches its own copy
   // (up to 8 x the K / V bytes over the fabric).  Remapped, the ids an XCD receives enumerate consecutive (query block, head, sample) items.
   int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  if (xcd_remap) {
+  if (KNOBS && xcd_remap) {
     const int total = gridDim.x * gridDim.y * gridDim.z;
     if ((total & 7) == 0) {
       const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -85,6 +87,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 
   V8 qf[QW][4];
   int qrow[QW];
+  // AQ: all eight Q loads of the wave's two query blocks are in flight before the first is converted (v3's emitted prologue waits for block 0's
+  // four loads, scales them, and only then issues block 1's: one more global round trip in front of the first key tile of every workgroup)
+  V8 qraw[QW][4];
 #pragma unroll
   for (int qb = 0; qb < QW; ++qb) {
     int q = q0 + qb * 32 + l31;
@@ -93,10 +98,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
     const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const V8 raw = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
+      qraw[qb][ks] = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
+      if constexpr (!AQ) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)raw[e] * p.scale_log2e);
+        for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)qraw[qb][ks][e] * p.scale_log2e);
+      }
     }
+  }
+  if constexpr (AQ) {
+    asm volatile("" : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]));
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)qraw[qb][ks][e] * p.scale_log2e);
   }
 
   // ---- LDS-DMA staging: one instruction = 8 rows x 128 B; wave w moves row blocks w and w + 4 of the K tile and of the V^T tile

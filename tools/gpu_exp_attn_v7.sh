@@ -16,10 +16,10 @@ timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "row_major_v_att
 grep -q passed $O/exp_attn_v7_test.log || exit 1
 grep -q failed $O/exp_attn_v7_test.log && exit 1
 timeout 300 python tools/attn_bench.py 3 7 8 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_bench.log
-# the lockstep question (header of tools/exp/attn_v7.h): second workgroup of every CU started 10 / 20 / 40 us late
-timeout 300 python tools/attn_bench.py 7 0xa07 0x1407 0x2807 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_stagger.log
-# ... and the XCD-aware block order (bit 16: the query blocks of one (sample, head) on ONE XCD's L2 instead of up to eight), alone and with variant 8
-timeout 300 python tools/attn_bench.py 7 0x10007 8 0x10008 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_xcd.log
+# the lockstep question (header of tools/exp/attn_v7.h): half of the first-round workgroups started 10 / 20 / 40 us late (variant 9 = 8 + the knobs)
+timeout 300 python tools/attn_bench.py 8 0xa09 0x1409 0x2809 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_stagger.log
+# ... and the XCD-aware block order (bit 16: the query blocks of one (sample, head) on ONE XCD's L2 instead of up to eight), against variant 8 and the knob-carrying kernel without it
+timeout 300 python tools/attn_bench.py 8 9 0x10009 2>&1 | grep -v libdrm | tee $O/exp_attn_v7_xcd.log
 # 4. the whole benchmark with the self-attention calls on kernel 7 (tools/exp/rowmajor_v_patch.py: the product's Python unchanged, transpose_v skipped);
 #    the baseline line on the same box is gpu_exp_v13.sh's variant-0 run (tools/gpu_round5_first.sh runs both in one call)
 if [ "${BENCH:-1}" = 1 ]; then
