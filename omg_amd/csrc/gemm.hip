@@ -975,11 +975,13 @@ int launch(const GemmP& p, hipStream_t s) {
       }
     }
     // 31: gemm_kernel_v11, schedule 5 with the short way to the first LDS-DMA (gemm_v11.h, SCH == 10: launch parameters in one batch, adapter id through the scalar cache)
-    if (v == 31 && v6ok) return launch_v11_form<T, CONV, 10>(p, s, mrows);
     // 27 / 28: gemm_kernel_v13 (tools/exp/gemm_v13.h) — the 256 x 320 tile, register-direct / transposed streaming epilogue; GEGLU stays on 256 x 256
     if ((v == 27 || v == 28) && v6ok && p.act == OMG_ACT_GEGLU) v = 25;
+    if (v == 32 && v6ok && p.act == OMG_ACT_GEGLU) v = 31;                              // 32 = 28 + the short prologue; its GEGLU fallback carries it too
     if (v == 27 && v6ok) return launch_v13_form<T, CONV, false>(p, s, mrows);
     if (v == 28 && v6ok) return launch_v13_form<T, CONV, true>(p, s, mrows);
+    if (v == 32 && v6ok) return launch_v13_form<T, CONV, true, true>(p, s, mrows);
+    if (v == 31 && v6ok) return launch_v11_form<T, CONV, 10>(p, s, mrows);
     // 45..48: gemm_kernel_v12 (tools/exp/gemm_v12.h) — 45 early residual DMA only; 46 persistent (+ early residual); 47 + next-tile prefetch; 48 + counted wait
     if (v >= 45 && v <= 48 && v6ok) {
       switch (v) {

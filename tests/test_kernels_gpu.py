@@ -407,6 +407,7 @@ def _experimental_variants():
         exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in names)
         v12 = (45, 46, 47, 48) if any("gemm_kernel_v12" in n for n in names) else ()      # next round's experiment (tools/exp/gemm_v12.h)
         v13 = (27, 28) if any("gemm_kernel_v13" in n for n in names) else ()              # the 256 x 320 tile (tools/exp/gemm_v13.h)
+        v13 += (32,) if any("gemm_kernel_v13" in n and "ELb1ELb1EEEv" in n for n in names) else ()      # ... with the short prologue of variant 31
         v31 = (31,) if any("gemm_kernel_v11" in n and "ELi10EEEv" in n for n in names) else ()      # schedule 5 with the short way to the first LDS-DMA
         found = ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v31 + v13 + v12
         only = os.environ.get("OMG_EXP_ONLY")                # "27,28": one experiment's variants, so that another's failure is not charged to it
@@ -501,7 +502,7 @@ def test_experimental_256x320_tile_is_bitwise_the_other_tiles(dev, K):
     the last tile's columns end inside a 128-column group; N = 192: the odd blocks lie outside the matrix); K = 64 / 128 / 192 have no
     steady-state stage (one, two, three stages: the peeled copies only); weight slots with a skipped group; per-row group bias + SiLU (form 4),
     residual (form 5); convolutions with the group bias folded.  Bitwise against variant 1."""
-    ev = tuple(v for v in _experimental_variants() if v in (27, 28, 31))      # 31 (gemm_v11.h, SCH == 10: adapter id through the scalar cache) rides along for
+    ev = tuple(v for v in _experimental_variants() if v in (27, 28, 31, 32))      # 31 (gemm_v11.h, SCH == 10: adapter id through the scalar cache) rides along for
     if not ev:                                                                 # this test's weight-slot cases; it falls back to its own tile for GEGLU like 27 / 28
         pytest.skip("product build: no gemm_kernel_v13")
     lib = L.lib()

@@ -1,4 +1,4 @@
-// tools/exp/gemm_v13.h — EXPERIMENT for round 5 (built by `make -C omg_amd/csrc EXP=1` only — variants 27 / 28; never part of the product library).
+// tools/exp/gemm_v13.h — EXPERIMENT for round 5 (built by `make -C omg_amd/csrc EXP=1` only — variants 27 / 28 / 32; never part of the product library).
 // WRITTEN IN ROUND 4 WITH NO GPU TIME LEFT: compiled for gfx950 and inspected (registers, scratch, accumulator traffic, instruction placement), NOT RUN.
 // tests/test_kernels_gpu.py compares these variants bit for bit with variant 1 as soon as an EXP build meets a GPU; tools/ksched_ab.py times them.
 //
@@ -178,7 +178,9 @@ OMG_DEV void epilogue13(const GemmP& p, f32x16 (&acc)[4][5], int lane, int wm0, 
   else epilogue_rows13<T, false, true, XE>(p, acc, cx, cx4, lane_col4, has_gb);
 }
 
-template <typename T, bool CONV, int EF, bool XE>
+// FP (variant 32 = 28 + this): the short way to the first LDS-DMA of gemm_v11.h's SCH == 10 — launch parameters requested in one batch, the group's
+// adapter id through the scalar cache — so that the two experiments can also be timed together
+template <typename T, bool CONV, int EF, bool XE, bool FP = false>
 __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
   constexpr int MT = 4, NT = 5;
   constexpr int BM_ = MT * 64, BN_ = NT * 64, BKc = 64;
@@ -190,6 +192,12 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
   static_assert(2 * STAGE_BYTES <= 160 * 1024, "two stages in LDS");
 
+  if constexpr (FP) {
+    asm volatile("" ::"s"(p.M), "s"(p.N), "s"(p.K), "s"(p.A), "s"(p.lda), "s"(p.W), "s"(p.ldw), "s"(p.tile_groups), "s"(p.rows_per_group),
+                 "s"(p.group_adapter), "s"(p.w_adapter_stride), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.dbg), "s"(p.bias), "s"(p.group_bias), "s"(p.ldgb));
+    if constexpr (CONV)
+      asm volatile("" ::"s"(p.Hin), "s"(p.Win), "s"(p.C1), "s"(p.C2), "s"(p.Hout), "s"(p.Wout), "s"(p.ksize), "s"(p.stride), "s"(p.upsample), "s"(p.X2));
+  }
   const bool ts_on = (p.dbg & 16) && blockIdx.x < 8192 && threadIdx.x == 0;      // tools/gemm_timeline.py: per-block time stamps
   long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (p.dbg & 16) ts0 = __builtin_amdgcn_s_memrealtime();
@@ -224,7 +232,10 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
   const int m0 = m_base + tm * BM_;
   const int n0 = tn * BN_;
   int adapter = 0;
-  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
+  if (p.group_adapter != nullptr) {
+    if constexpr (FP) adapter = *(const __attribute__((address_space(4))) int*)(p.group_adapter + grp);
+    else adapter = p.group_adapter[grp];
+  }
   if (p.w_adapter_stride != 0 && adapter < 0) return;
   const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
   const int nk = (p.K + BKc - 1) / BKc;
@@ -419,27 +430,27 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
 }
 #undef OMG_V13_COL
 
-template <typename T, bool CONV, int EF, bool XE>
+template <typename T, bool CONV, int EF, bool XE, bool FP = false>
 int launch_v13(GemmP p, hipStream_t s, int mrows) {
   constexpr int lds = 2 * (256 + 320) * 64 * 2;
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v13<T, CONV, EF, XE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v13<T, CONV, EF, XE, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + 255) / 256;
   p.tiles_n = (p.N + 319) / 320;
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v13<T, CONV, EF, XE>), dim3(grid), dim3(256), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v13<T, CONV, EF, XE, FP>), dim3(grid), dim3(256), lds, s, p);
   return omg_check_launch("gemm_v13");
 }
 // GEGLU problems are not this tile's (header): the caller sends them to the 256 x 256 kernel
-template <typename T, bool CONV, bool XE>
+template <typename T, bool CONV, bool XE, bool FP = false>
 int launch_v13_form(const GemmP& p, hipStream_t s, int mrows) {
   const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
-  if (gb_rows || p.act == OMG_ACT_SILU) return launch_v13<T, CONV, 4, XE>(p, s, mrows);
-  if (p.residual != nullptr) return launch_v13<T, CONV, 5, XE>(p, s, mrows);
-  return launch_v13<T, CONV, 1, XE>(p, s, mrows);
+  if (gb_rows || p.act == OMG_ACT_SILU) return launch_v13<T, CONV, 4, XE, FP>(p, s, mrows);
+  if (p.residual != nullptr) return launch_v13<T, CONV, 5, XE, FP>(p, s, mrows);
+  return launch_v13<T, CONV, 1, XE, FP>(p, s, mrows);
 }

@@ -12,7 +12,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05
 mkdir -p $O
-OMG_EXP_ONLY=27,28 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "(variants_are_bitwise and dtype0) or 256x320_tile" 2>&1 | tail -8 | tee $O/exp_v13_test.log
+OMG_EXP_ONLY=27,28,32 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "(variants_are_bitwise and dtype0) or 256x320_tile" 2>&1 | tail -8 | tee $O/exp_v13_test.log
 grep -q passed $O/exp_v13_test.log || exit 1
 grep -q failed $O/exp_v13_test.log && exit 1
 timeout 300 python tools/ksched_ab.py 0,27,28 3 conv320 2>&1 | grep -v libdrm | tee $O/exp_v13_ab_conv320.log

@@ -21,7 +21,7 @@ bash tools/gpu_exp_v12.sh; V12_RC=$?
 # transformer Linears as the fused steps launch them (64 weight slots) and on the plain shapes
 OMG_EXP_ONLY=31 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -k "(variants_are_bitwise and dtype0) or 256x320_tile" 2>&1 | tail -3 | tee gpurun_out/r05/exp_v31_test.log
 if grep -q passed gpurun_out/r05/exp_v31_test.log && ! grep -q failed gpurun_out/r05/exp_v31_test.log; then
-  timeout 300 python tools/ksched_ab.py 25,31 3 slots 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_v31_ab_slots.log
+  timeout 300 python tools/ksched_ab.py 25,31,28,32 3 slots 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_v31_ab_slots.log      # 32 = the 256 x 320 tile (28) with the same prologue
   timeout 300 python tools/ksched_ab.py 25,31 3 k 2>&1 | grep -v libdrm | tee gpurun_out/r05/exp_v31_ab_k.log
 fi
 # conv_out with the weight slice in registers (tools/exp/conv_out_v2.h; 0.45 % of the step at 14x its memory time): bitwise, then the two kernels timed
