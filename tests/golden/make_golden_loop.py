@@ -1,0 +1,433 @@
+"""Pin the loop / fusion / processor half of the oracle by EXECUTING THE REFERENCE'S OWN PIPELINE CODE in this container.
+
+    python tests/golden/make_golden_loop.py       (needs /root/reference; writes loop_golden.npz next to itself)
+
+``/root/reference/src/pipelines/lora_pipeline.py`` fails to import only because of its ``from diffusers ...`` / ``from torchvision ...``
+lines (:16-57).  This script registers stand-in modules for exactly those names (test infrastructure — the same trick
+``make_golden.py`` plays for ``cv2``), imports the file UNMODIFIED and drives the reference's own
+
+  * ``LoraMultiConceptPipeline.__call__``            lora_pipeline.py:211-669  (prompt / batch layout, loop :485-632, fusion :568-607, CFG :610-612)
+  * ``LoraMultiConceptPipeline.get_region_mask``     lora_pipeline.py:674-681
+  * ``RegionControlNet_AttnProcessor.__call__``      lora_pipeline.py:61-133
+  * ``revise_regionally_controlnet_forward``         lora_pipeline.py:136-152
+  * ``AttentionReplace`` (the controller)            src/prompt_attention/p2p_attention.py (real, as in make_golden.py)
+
+What the stand-ins supply — and therefore what this fixture does NOT pin (all third-party ``diffusers==0.25.0`` / ``peft==0.8.2`` code):
+  * the base class ``StableDiffusionXLControlNetPipeline``: ``encode_prompt`` returns embeddings from a table keyed by the prompt string,
+    ``prepare_latents`` multiplies the given latents by ``init_noise_sigma``, ``_get_add_time_ids`` concatenates its three tuples,
+    ``progress_bar`` / ``maybe_free_model_hooks`` / ``upcast_vae`` do nothing;
+  * the UNet: the ORACLE's functional forward (oracle/unet.py) for everything outside attention, behind an ``nn.Module`` tree whose attention
+    layers are ``Attention``-protocol modules (class name 'Attention', ``to_q/to_k/to_v/to_out``, ``head_to_batch_dim``, ``get_attention_scores`` =
+    softmax(baddbmm), ``set_processor``) so that the reference's installer walks it and the reference's processor + controller run for real at
+    every attention layer of the main UNet; the concept UNet keeps a default processor = ``F.scaled_dot_product_attention`` (AttnProcessor2_0);
+  * the scheduler: the oracle's DDIM / Euler behind the diffusers scheduler API (``set_timesteps``, ``timesteps``, ``scale_model_input``, ``step``);
+  * ``concept_models``: ``set_adapters`` records the active (adapter, weight) list PEFT-style, the LoRA deltas are the oracle's synthetic ones.
+
+The stored trajectories (per-step latents of stage 1 and stage 2) are compared in tests/test_oracle.py with ``oracle/pipeline.denoise`` +
+``oracle/controller.reference_attn_fn`` to <= 1e-5: after that, A1 / A3 / A7 / A8 / A9 of the oracle are "pinned by the reference run here",
+and every GPU loop test (which compares the HIP path with that oracle) inherits the pin.
+"""
+import contextlib
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import schedulers as osched  # noqa: E402
+from oracle import unet as ou  # noqa: E402
+from oracle.controller import WhitespaceTokenizer  # noqa: E402  (tokenizer only: no CLIP vocabulary offline)
+
+
+# ----------------------------------------------------------------------------------------------------------------- stand-in modules
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class StubPipelineBase:
+    """What lora_pipeline.py uses of diffusers' StableDiffusionXLControlNetPipeline / DiffusionPipeline."""
+
+    def register_modules(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def register_to_config(self, **kw):
+        self.config = _Cfg(kw)
+
+    _execution_device = torch.device("cpu")
+    guidance_scale = property(lambda s: s._guidance_scale)
+    clip_skip = property(lambda s: s._clip_skip)
+    cross_attention_kwargs = property(lambda s: s._cross_attention_kwargs)
+    num_timesteps = property(lambda s: s._num_timesteps)
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1 and self.unet.config.time_cond_proj_dim is None
+
+    embed_table = None       # prompt string -> (embeds (77, D), pooled (P,))
+
+    def encode_prompt(self, prompt=None, prompt_2=None, device=None, num_images_per_prompt=1, do_classifier_free_guidance=True,
+                      negative_prompt=None, negative_prompt_2=None, prompt_embeds=None, negative_prompt_embeds=None,
+                      pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None, lora_scale=None, clip_skip=None):
+        def look(p):
+            ps = [p] if isinstance(p, str) else list(p)
+            return torch.stack([self.embed_table[s][0] for s in ps]), torch.stack([self.embed_table[s][1] for s in ps])
+        e, p = look(prompt)
+        ne, np_ = look(negative_prompt)
+        return e, ne, p, np_
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        assert latents is not None, "the fixture injects the initial noise (inference_lora.py:267 draws it on the device)"
+        return latents.to(device) * self.scheduler.init_noise_sigma
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        return {}
+
+    def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype, text_encoder_projection_dim=None):
+        return torch.tensor([list(original_size + crops_coords_top_left + target_size)], dtype=dtype)
+
+    @contextlib.contextmanager
+    def progress_bar(self, total=None):
+        yield types.SimpleNamespace(update=lambda: None)
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    def upcast_vae(self):
+        pass
+
+
+class StubControlNetModel(nn.Module):
+    config = _Cfg(global_pool_conditions=False)
+    dtype = torch.float32
+
+
+class StubMultiControlNetModel(nn.Module):
+    pass
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__golden_stub__ = True
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        sys.modules[name] = m
+        parent, _, leaf = name.rpartition(".")
+        if parent:
+            setattr(sys.modules[parent], leaf, m)
+        return m
+
+    class _Any:                    # a name that is only ever imported / used as an annotation
+        pass
+
+    # transformers decides at ITS import whether torchvision exists: resolve the names lora_pipeline.py:8-14 imports before the stand-in is registered
+    from transformers import CLIPImageProcessor, CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer, CLIPVisionModelWithProjection  # noqa: F401
+    log = types.SimpleNamespace(get_logger=lambda name: types.SimpleNamespace(warning=print, info=lambda *a, **k: None))
+    mod("diffusers", StableDiffusionXLControlNetPipeline=StubPipelineBase)
+    mod("diffusers.utils", USE_PEFT_BACKEND=True, deprecate=lambda *a, **k: None, logging=log, replace_example_docstring=lambda s: (lambda f: f),
+        scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None, load_image=lambda *a, **k: None)
+    mod("diffusers.utils.import_utils", is_invisible_watermark_available=lambda: False)
+    mod("diffusers.utils.torch_utils", is_compiled_module=lambda m: False, is_torch_version=lambda op, v: True, randn_tensor=None)
+    mod("diffusers.image_processor", PipelineImageInput=_Any, VaeImageProcessor=lambda **k: None)
+    mod("diffusers.loaders", FromSingleFileMixin=_Any, IPAdapterMixin=_Any, StableDiffusionXLLoraLoaderMixin=_Any, TextualInversionLoaderMixin=_Any)
+    mod("diffusers.models", AutoencoderKL=_Any, ControlNetModel=StubControlNetModel, ImageProjection=_Any, UNet2DConditionModel=_Any)
+    mod("diffusers.models.attention_processor", AttnProcessor2_0=_Any, LoRAAttnProcessor2_0=_Any, LoRAXFormersAttnProcessor=_Any, XFormersAttnProcessor=_Any)
+    mod("diffusers.models.lora", adjust_lora_scale_text_encoder=lambda *a, **k: None)
+    mod("diffusers.schedulers", KarrasDiffusionSchedulers=_Any)
+    mod("diffusers.pipelines")
+    mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=StubPipelineBase)
+    mod("diffusers.pipelines.stable_diffusion_xl")
+    mod("diffusers.pipelines.stable_diffusion_xl.pipeline_output", StableDiffusionXLPipelineOutput=lambda images: types.SimpleNamespace(images=images))
+    mod("diffusers.pipelines.controlnet")
+    mod("diffusers.pipelines.controlnet.multicontrolnet", MultiControlNetModel=StubMultiControlNetModel)
+    mod("torchvision")
+    mod("torchvision.transforms")
+    mod("torchvision.transforms.functional", to_tensor=None)
+    mod("torchvision.utils", save_image=None)
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+
+
+# --------------------------------------------------------------------------------------------- the UNet behind the diffusers module protocol
+class LoraLinear(nn.Module):
+    """PEFT-style wrapped Linear: base(x) + sum over the ACTIVE adapters of weight * scale * B(A(x)).  `state` is shared by the whole UNet and
+    holds what set_adapters / the forward's cross_attention_kwargs["scale"] selected."""
+
+    def __init__(self, weight, bias, key, state):
+        super().__init__()
+        self.weight, self.bias, self.key, self.state = weight, bias, key, state
+
+    def forward(self, x):
+        y = F.linear(x, self.weight, self.bias)
+        return y + self.state.delta(self.key, x)
+
+
+class LoraState:
+    def __init__(self):
+        self.adapters = {}           # name -> {key: (A, B)}
+        self.active = ()             # ((name, weight), ...)
+        self.scale = 1.0             # cross_attention_kwargs["scale"] of the running forward (PEFT: scale_lora_layers)
+
+    def delta(self, key, x):
+        d = 0.0
+        for name, w in self.active:
+            ab = self.adapters[name].get(key)
+            if ab is not None:
+                d = d + (w * self.scale) * F.linear(F.linear(x, ab[0]), ab[1])
+        return d
+
+
+class Attention(nn.Module):          # the class NAME is what revise_regionally_controlnet_forward looks for (lora_pipeline.py:139)
+    """diffusers.models.attention_processor.Attention, the attributes and helpers the reference's processor reads (lora_pipeline.py:81-131)."""
+
+    def __init__(self, sd, name, heads, state):
+        super().__init__()
+        lin = lambda n, b=None: LoraLinear(sd[f"{name}.{n}.weight"], sd.get(f"{name}.{n}.bias") if b else None, f"{name}.{n}", state)
+        self.to_q, self.to_k, self.to_v = lin("to_q"), lin("to_k"), lin("to_v")
+        self.to_out = nn.ModuleList([lin("to_out.0", True), nn.Dropout(0.0)])
+        self.heads = heads
+        self.scale = (self.to_q.weight.shape[0] // heads) ** -0.5
+        self.group_norm = self.spatial_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.processor = sdpa_processor
+
+    def set_processor(self, p):
+        self.processor = p
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size):
+        assert attention_mask is None
+        return None
+
+    def head_to_batch_dim(self, t):
+        b, n, c = t.shape
+        return t.reshape(b, n, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, n, c // self.heads)
+
+    def batch_to_head_dim(self, t):
+        bh, n, d = t.shape
+        return t.reshape(bh // self.heads, self.heads, n, d).permute(0, 2, 1, 3).reshape(bh // self.heads, n, d * self.heads)
+
+    def get_attention_scores(self, query, key, attention_mask=None):
+        assert attention_mask is None
+        scores = torch.baddbmm(torch.empty(query.shape[0], query.shape[1], key.shape[1], dtype=query.dtype), query, key.transpose(-1, -2),
+                               beta=0, alpha=self.scale)
+        return scores.softmax(dim=-1)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states, **kw)
+
+
+def sdpa_processor(attn, hidden_states, encoder_hidden_states=None, **kw):
+    """AttnProcessor2_0 on (B, N, C) input: torch's own scaled_dot_product_attention."""
+    src = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+    b = hidden_states.shape[0]
+    split = lambda t: t.view(b, -1, attn.heads, t.shape[-1] // attn.heads).transpose(1, 2)
+    o = F.scaled_dot_product_attention(split(attn.to_q(hidden_states)), split(attn.to_k(src)), split(attn.to_v(src)))
+    o = o.transpose(1, 2).reshape(b, -1, attn.heads * o.shape[-1])
+    return attn.to_out[1](attn.to_out[0](o))
+
+
+class StubUNet(nn.Module):
+    """down_blocks / mid_block / up_blocks hold the Attention modules under their diffusers names; forward = the oracle's functional UNet with
+    every attention call routed through those modules (so through whatever processor the reference installed)."""
+
+    def __init__(self, sd, cfg):
+        super().__init__()
+        self.sd, self.cfg, self.state = sd, cfg, LoraState()
+        self.config = _Cfg(in_channels=cfg.in_channels, sample_size=cfg.sample_size, time_cond_proj_dim=None)
+        self.dtype = torch.float32
+        self.by_name = {}
+        heads = {}
+        rev = list(reversed(cfg.attention_head_dim))
+        for k in sd:
+            if k.endswith(".to_q.weight"):
+                name = k[: -len(".to_q.weight")]
+                parts = name.split(".")
+                h = cfg.attention_head_dim[int(parts[1])] if parts[0] == "down_blocks" else rev[int(parts[1])] if parts[0] == "up_blocks" else cfg.attention_head_dim[-1]
+                heads[name] = h
+        for name, h in heads.items():
+            node = self
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, nn.Module())
+                node = getattr(node, p)
+            a = Attention(sd, name, h, self.state)
+            node.add_module(parts[-1], a)
+            self.by_name[name] = a
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None, added_cond_kwargs=None, return_dict=True):
+        assert timestep_cond is None and return_dict is False
+        self.state.scale = (cross_attention_kwargs or {}).get("scale", 1.0)
+
+        def attention(sd, name, heads, x, ctx, attn_fn, lora=None):
+            return self.by_name[name](x, encoder_hidden_states=ctx)
+
+        saved, ou.attention = ou.attention, attention
+        try:
+            out = ou.unet_forward(self.sd, self.cfg, sample, float(timestep), encoder_hidden_states, added_cond_kwargs["text_embeds"],
+                                  added_cond_kwargs["time_ids"], lora=self.state.delta,
+                                  down_block_additional_residuals=down_block_additional_residuals,
+                                  mid_block_additional_residual=mid_block_additional_residual)
+        finally:
+            ou.attention = saved
+        return (out,)
+
+
+class SchedulerAdapter:
+    """The oracle's scheduler behind the diffusers API (set_timesteps / timesteps / scale_model_input / step / order / init_noise_sigma)."""
+    order = 1
+
+    def __init__(self, kind, n_steps):
+        self.o = osched.make(kind, n_steps)
+        self.init_noise_sigma = self.o.init_noise_sigma
+        self.n = n_steps
+
+    def set_timesteps(self, n, device=None):
+        assert n == self.n
+        self.timesteps = torch.as_tensor(np.asarray(self.o.timesteps, dtype=np.float64))
+
+    def _i(self, t):
+        return int((self.timesteps == t).nonzero()[0, 0])
+
+    def scale_model_input(self, x, t):
+        return self.o.scale_model_input(x, self._i(t)).float()
+
+    def step(self, noise, t, latents, return_dict=False, **kw):
+        out = self.o.step(noise.double().numpy(), self._i(t), latents.double().numpy())
+        return (torch.from_numpy(out).float(),)
+
+
+class ConceptModels(StubPipelineBase):
+    """The second pipeline object of inference_lora.py:166-170 as the loop uses it: unet, encode_prompt, _get_add_time_ids, set_adapters."""
+
+    def __init__(self, unet, table):
+        self.unet, self.embed_table = unet, table
+        self.calls = []
+
+    def set_adapters(self, names, adapter_weights=None):
+        names = [names] if isinstance(names, str) else list(names)
+        weights = adapter_weights or [1.0] * len(names)
+        self.unet.state.active = tuple(zip(names, weights))
+        self.calls.append(self.unet.state.active)
+
+
+# ------------------------------------------------------------------------------------------------------------------- the cases
+P = "a man and a woman walking on the street"
+NEG = "blurry low quality"
+REGION = [("a man wearing glasses", "ugly man"), ("a woman with red hair", "ugly woman"), ("a dog on a leash", "ugly dog")]
+
+
+def embed_table(cfg, dtype=torch.float32):
+    g = torch.Generator().manual_seed(77)
+    t = {}
+    for s in [P, NEG] + [x for r in REGION for x in r]:
+        t[s] = (torch.randn(77, cfg.cross_attention_dim, generator=g).to(dtype).float(),
+                torch.randn(cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim, generator=g).to(dtype).float())
+    return t
+
+
+def masks_for(H, W, kind):
+    m1 = torch.zeros(H, W); m1[H // 4:, W // 16: W // 2 - 8] = 1
+    m2 = torch.zeros(H, W); m2[H // 4:, W // 2 - 24: W - 8] = 1         # overlaps m1 (the sum rule of :603)
+    m3 = torch.zeros(H, W); m3[: H // 3, W // 3:] = 1
+    return {"overlap": [m1, m2], "none_mid": [m1, None, m2], "three": [m1, m2, m3]}[kind]
+
+
+CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, latent w)
+    ("ddim_overlap", "ddim", 20, 7.5, "overlap", False, (16, 16)),
+    ("euler_none_mid", "euler", 20, 7.5, "none_mid", False, (16, 16)),
+    ("ddim_style_three", "ddim", 18, 5.0, "three", True, (16, 16)),
+    ("ddim_nonsquare", "ddim", 18, 7.5, "overlap", False, (24, 16)),
+]
+LORA_RANK, LORA_SEED0, LORA_SCALE = 8, 100, 0.8
+
+
+def build(case):
+    """Everything a case needs, shared by this script and tests/test_oracle.py (which re-creates the inputs and runs the ORACLE's loop)."""
+    name, sched, steps, gs, mkind, style, (lh, lw) = case
+    cfg = ou.UNetConfig.tiny()
+    sd = ou.init_state_dict(cfg, seed=3)
+    table = embed_table(cfg)
+    H, W = lh * 8, lw * 8
+    masks = masks_for(H, W, mkind)
+    K = len(masks)
+    names = ou.lora_target_names(cfg)
+    loras = {f"c{c}": ou.make_lora(cfg, names, rank=LORA_RANK, seed=LORA_SEED0 + c, scale=1.0)[0] for c in range(K)}
+    loras["style"] = ou.make_lora(cfg, names, rank=LORA_RANK, seed=LORA_SEED0 + 50, scale=1.0)[0]
+    lat0 = torch.randn(1, 4, lh, lw, generator=torch.Generator().manual_seed(14))
+    return dict(name=name, sched=sched, steps=steps, gs=gs, style=style, cfg=cfg, sd=sd, table=table, H=H, W=W, masks=masks, K=K, loras=loras, lat0=lat0,
+                ctl_args=([P, P], 50 if name == "ddim_overlap" else steps, {"default_": 1.0}, 0.4, lw // 4, lh // 4))      # 50 = inference_lora.py:156
+
+
+def run_reference(c):
+    from src.pipelines.lora_pipeline import LoraMultiConceptPipeline, revise_regionally_controlnet_forward     # REFERENCE code
+    from src.prompt_attention.p2p_attention import AttentionReplace                                          # REFERENCE code
+
+    main_unet, concept_unet = StubUNet(c["sd"], c["cfg"]), StubUNet(c["sd"], c["cfg"])
+    concept_unet.state.adapters = c["loras"]
+    if c["style"]:                                         # inference_lora.py:162-164: the style LoRA is loaded into BOTH pipes
+        main_unet.state.adapters = {"style": c["loras"]["style"]}
+        main_unet.state.active = (("style", 1.0),)
+    vae = nn.Module()
+    vae.config = _Cfg(block_out_channels=(1, 2, 3, 4), force_upcast=True, scaling_factor=0.13025)
+    vae.dtype = torch.float32
+    vae.post_quant_conv = nn.Conv2d(4, 4, 1)
+    pipe = LoraMultiConceptPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=main_unet,
+                                    controlnet=StubControlNetModel(), scheduler=SchedulerAdapter(c["sched"], c["steps"]))
+    pipe.embed_table = c["table"]
+    concept = ConceptModels(concept_unet, c["table"])
+    controller = AttentionReplace(*c["ctl_args"], tokenizer=WhitespaceTokenizer(), device="cpu", dtype=torch.float32)
+    revise_regionally_controlnet_forward(pipe.unet, controller)
+    out = {"num_att_layers": np.array(controller.num_att_layers)}
+    for stage in (1, 2):
+        controller.reset()
+        traj = []
+        real_step = pipe.scheduler.step
+
+        def step(*a, **k):
+            r = real_step(*a, **k)
+            traj.append(r[0].clone())
+            return r
+        pipe.scheduler.step = step
+        res = pipe(prompt=[[P, P], [REGION[k] for k in range(c["K"])]], negative_prompt=[NEG, NEG], image=None, height=c["H"], width=c["W"],
+                   num_inference_steps=c["steps"], guidance_scale=c["gs"], latents=c["lat0"].clone(), cross_attention_kwargs={"scale": LORA_SCALE},
+                   controller=controller, concept_models=concept, stage=stage, region_masks=c["masks"], lora_list=[f"c{k}" for k in range(c["K"])],
+                   styleL=c["style"], output_type="latent")
+        pipe.scheduler.step = real_step
+        assert torch.equal(res.images, traj[-1])
+        assert (controller.cur_step, controller.cur_att_layer) == (c["steps"], 0)
+        out[f"stage{stage}"] = torch.stack(traj).numpy()
+    out["set_adapters_calls"] = np.array(len(concept.calls))
+    return out
+
+
+def main():
+    install_stubs()
+    blob = {}
+    for case in CASES:
+        c = build(case)
+        r = run_reference(c)
+        for k, v in r.items():
+            blob[f"{c['name']}/{k}"] = v
+        d = np.abs(r["stage2"][-1][1] - r["stage1"][-1][1]).max()
+        print(f"{c['name']}: {c['steps']} steps, layers {int(r['num_att_layers'])}, stage-2 edit vs stage-1 max|d| = {d:.3f}, "
+              f"base sample equal: {np.abs(r['stage2'][-1][0] - r['stage1'][-1][0]).max():.2e}")
+    np.savez_compressed(os.path.join(HERE, "loop_golden.npz"), **blob)
+    print("wrote", os.path.join(HERE, "loop_golden.npz"), sum(v.nbytes for v in blob.values()) // 1024, "KiB raw")
+
+
+if __name__ == "__main__":
+    main()

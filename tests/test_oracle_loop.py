@@ -1,0 +1,83 @@
+"""CPU tests (-m "not gpu"): the oracle's LOOP (oracle/pipeline.py denoise / fuse_noise / region_union / cfg) and its attention-processor
+sequence (oracle/controller.py reference_attn_fn + AttentionReplaceOracle) against trajectories produced by EXECUTING THE REFERENCE'S OWN
+``LoraMultiConceptPipeline.__call__`` / ``RegionControlNet_AttnProcessor`` / ``revise_regionally_controlnet_forward`` /
+``get_region_mask`` / ``AttentionReplace`` in the build container (tests/golden/make_golden_loop.py -> loop_golden.npz).
+
+This is the pin of SURVEY §8 rows A1, A3, A7, A8, A9 (and of A11's adapter bookkeeping: set_adapters, [lora, "style"] at [0.7, 0.5]):
+the GPU loop tests compare the HIP pipeline with exactly these oracle functions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import controller as oc
+from oracle import pipeline as opipe
+from oracle import schedulers as osched
+from oracle import unet as ou
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLD)
+import make_golden_loop as mk  # noqa: E402   (only `build`, CASES and the prompt strings: no reference import happens at module import)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "loop_golden.npz"))
+
+
+def oracle_run(c, stage, num_att_layers):
+    cfg, sd, table, S = c["cfg"], c["sd"], c["table"], c["steps"]
+    osch = osched.make(c["sched"], S)
+    octl = oc.AttentionReplaceOracle(*c["ctl_args"])
+    octl.num_att_layers = num_att_layers
+    attn = oc.reference_attn_fn(octl)
+    # lora_pipeline.py:467-474: [neg, neg, pos, pos]; time ids repeated per row (:474)
+    ctx4 = torch.stack([table[mk.NEG][0]] * 2 + [table[mk.P][0]] * 2)
+    te4 = torch.stack([table[mk.NEG][1]] * 2 + [table[mk.P][1]] * 2)
+    tid = torch.tensor([[c["H"], c["W"], 0, 0, c["H"], c["W"]]], dtype=torch.float32)
+    names = ou.lora_target_names(cfg)
+    fn = {k: ou.make_lora(cfg, names, rank=mk.LORA_RANK, seed=mk.LORA_SEED0 + (50 if k == "style" else int(k[1:])), scale=mk.LORA_SCALE)[1] for k in c["loras"]}
+    main_lora = fn["style"] if c["style"] else None              # inference_lora.py:162-164 + the main call's scale 0.8 (:546-566)
+
+    def main(x, i):
+        return ou.unet_forward(sd, cfg, x, float(osch.timesteps[i]), ctx4, te4, tid.repeat(4, 1), attn_fn=attn, lora=main_lora)
+
+    def conc(k):
+        rp, rn = mk.REGION[k]
+        ctx2 = torch.stack([table[rn][0], table[rp][0]])          # :345: [negative, positive]
+        te2 = torch.stack([table[rn][1], table[rp][1]])
+        if c["style"]:                                            # :588-589: set_adapters([lora, "style"], adapter_weights=[0.7, 0.5])
+            lora = lambda key, x: 0.7 * fn[f"c{k}"](key, x) + 0.5 * fn["style"](key, x)
+        else:
+            lora = fn[f"c{k}"]
+        return lambda x, i: ou.unet_forward(sd, cfg, x, float(osch.timesteps[i]), ctx2, te2, tid.repeat(2, 1), lora=lora)
+
+    rec = []
+    opipe.denoise(main, [conc(k) for k in range(c["K"])], osch, c["lat0"] * osch.init_noise_sigma, S, c["gs"], stage, masks=c["masks"], record=rec)
+    assert (octl.cur_step, octl.cur_att_layer) == (S, 0)
+    return torch.stack(rec).numpy()
+
+
+@pytest.mark.parametrize("case", mk.CASES, ids=[c[0] for c in mk.CASES])
+def test_oracle_loop_matches_the_reference_pipeline_run_here(gold, case):
+    c = mk.build(case)
+    nl = int(gold[f"{c['name']}/num_att_layers"])
+    assert nl == 2 * ou.count_attention_layers(c["cfg"])          # lora_pipeline.py:152
+    for stage in (1, 2):
+        ref = gold[f"{c['name']}/stage{stage}"]
+        got = oracle_run(c, stage, nl)
+        assert got.shape == ref.shape == (c["steps"], 2, 4) + tuple(c["lat0"].shape[2:])
+        err = np.abs(got - ref).reshape(c["steps"], -1).max(axis=1)
+        rms = float(np.sqrt((ref[-1] ** 2).mean()))
+        print(f"{c['name']} stage {stage}: max|d| per step first/last = {err[0]:.2e} / {err[-1]:.2e}, latent rms {rms:.3f}")
+        # fp32 on both sides; the only differences are summation order (SDPA vs softmax-bmm in the concept pass, einsum vs expand in the
+        # controller) amplified by CFG over <= 20 steps
+        assert err.max() < 2e-6 * max(1.0, rms), err            # measured: stage 1 bit-equal, stage 2 <= 7.6e-6 at latent rms 16
+    s1, s2 = gold[f"{c['name']}/stage1"], gold[f"{c['name']}/stage2"]
+    assert np.array_equal(s1[:16], s2[:16]), "stage 2 equals stage 1 until the first fused step (i > 15, lora_pipeline.py:568)"
+    assert np.abs(s2[-1][1] - s1[-1][1]).max() > 0.1 and np.array_equal(s2[:, 0], s1[:, 0])
+    # one set_adapters per concept at prompt encoding (:340-342) + one per concept WITH a mask per fused step (:588-591), both stages
+    n_masked = sum(m is not None for m in c["masks"])
+    assert int(gold[f"{c['name']}/set_adapters_calls"]) == 2 * c["K"] + n_masked * (c["steps"] - 16)
