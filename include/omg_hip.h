@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMG_ABI_VERSION 5
+#define OMG_ABI_VERSION 6
 
 enum { OMG_F16 = 0, OMG_BF16 = 1, OMG_F32 = 2 /* only where a signature says so */ };
 
@@ -199,13 +199,19 @@ typedef struct {
   const void* Q; int64_t ldq; int64_t q_bstride;   /* row stride / batch stride (elements) */
   const void* K; int64_t ldk; int64_t k_bstride;
   const void* Vt;             /* [B, heads, 64, Nkv_pad] from omg_transpose_v (its key order); columns >= Nkv MUST be zero (it writes
-                                 them so): the self-attention kernel masks no score, the padded keys cancel against those zeros */
+                                 them so): attn_fwd_kernel3 masks no score, the padded keys cancel against those zeros.  May be
+                                 NULL when V (below) is given and Nkv > 128 */
   int32_t Nkv_pad;            /* % 64 == 0                                            */
   const int32_t* qk_src;      /* device [B]: batch index supplying Q,K; NULL = identity */
   float scale;
   int32_t accumulate;         /* 0: O = out_scale*attn ; 1: O += out_scale*attn       */
   float out_scale;
   void* O; int64_t ldo; int64_t o_bstride;
+  /* ABI 6: V ROW-MAJOR — [B, Nkv, (head, 64)] with row stride ldv and batch stride v_bstride (elements, both % 8 == 0), i.e. the V
+   * columns of the fused QKV projection's output exactly as omg_gemm wrote them.  When given and Nkv > 128 (self-attention) the kernel
+   * stages it like K and transposes on the LDS read (ds_read_b64_tr_b16): no omg_transpose_v pass, Vt / Nkv_pad may be NULL / 0.
+   * With Nkv <= 128 pass Vt (the resident-K/V kernels want the V^T image); V alone is rejected there.  NULL = ABI 5 behaviour. */
+  const void* V; int64_t ldv; int64_t v_bstride;
 } omg_attn_args;
 
 int omg_attn_fwd(const omg_attn_args* a, void* stream);

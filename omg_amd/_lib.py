@@ -85,6 +85,7 @@ class AttnArgs(C.Structure):
         ("Vt", c_vp), ("Nkv_pad", c_i32),
         ("qk_src", c_vp), ("scale", c_f32), ("accumulate", c_i32), ("out_scale", c_f32),
         ("O", c_vp), ("ldo", c_i64), ("o_bstride", c_i64),
+        ("V", c_vp), ("ldv", c_i64), ("v_bstride", c_i64),       # ABI 6: row-major V of the self-attention (no transpose pass)
     ]
 
 
@@ -167,7 +168,7 @@ def lib() -> C.CDLL:
         fn = getattr(l, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if l.omg_abi_version() != 5:
+    if l.omg_abi_version() != 6:
         raise OmgHipError("libomg_hip.so ABI version mismatch; rebuild")
     v = os.environ.get("OMG_GEMM_VARIANT")      # debugging/benchmarking aid: force one GEMM tile configuration
     if v:

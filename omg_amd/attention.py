@@ -163,7 +163,7 @@ class Attention(nn.Module):
                     self._mx8["qkv"] = ops.quant_mx8(self.qkv_weight())
                 qkv = ops.gemm_mx8(xq, self._mx8["qkv"], out_dtype=self.to_q.weight.dtype)
             qkv = qkv.view(B, N, 3 * inner)
-            return qkv[:, :, :inner], qkv[:, :, inner:2 * inner], ops.transpose_v(qkv[:, :, 2 * inner:], self.heads)
+            return qkv[:, :, :inner], qkv[:, :, inner:2 * inner], ops.value_operand(qkv[:, :, 2 * inner:], self.heads)
         if self._has_lora():
             q = self.to_q(x); k = self.to_k(x); v = self.to_v(x)
         else:
@@ -174,7 +174,7 @@ class Attention(nn.Module):
                 qkv = ops.gemm(x.reshape(B * N, C), self.qkv_weight())
             qkv = qkv.view(B, N, 3 * inner)
             q, k, v = qkv[:, :, :inner], qkv[:, :, inner:2 * inner], qkv[:, :, 2 * inner:]
-        return q, k, ops.transpose_v(v, self.heads)
+        return q, k, ops.value_operand(v, self.heads)
 
     def project_cross(self, ctx: torch.Tensor):
         """ctx (B,Nk,Cx) -> K view and V^T of a constant ``encoder_hidden_states``.

@@ -625,9 +625,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
   }
 }
 
-#ifdef OMG_EXP_KSCHED
-#include "attn_v7.h"       // tools/exp/ (make EXP=1 adds the include path): round 5's experiment — V read row-major through ds_read_b64_tr_b16, NOT RUN yet
-#endif
+#include "attn_v7.h"       // attn_fwd_kernel7: the self-attention kernel — V read row-major through ds_read_b64_tr_b16, XCD-aware block order
 
 // V[B, Nkv, heads*64] -> Vt[B, heads, 64, Nkv_pad]; grid (Nkv_pad/64, heads, B)
 template <typename T>
@@ -756,46 +754,34 @@ AttnP make_params(const omg_attn_args* a) {
   return p;
 }
 
-int g_attn_variant = 0;      // 0 = heuristic (v3 above 128 keys, v6 up to 128, v2 when O is not 16-byte aligned), 2 / 3 / 6 force one; tools / A-B tests only
+int g_attn_variant = 0;      // 0 = heuristic (above 128 keys: v7 when V is given row-major, else v3; v6 up to 128; v2 when O is not 16-byte aligned), 2 / 3 / 6 force one; tools / A-B tests only
 
 }  // namespace
 
 static int g_attn_qchunk = 512;     // v6: query rows per workgroup strip (tools: bits 8.. of the variant word, in units of 128)
 
 extern "C" void omg_debug_set_attn_variant(int v) { g_attn_variant = v & 0xff; g_attn_qchunk = (v >> 8) ? (v >> 8) * 128 : 512; }
-#ifdef OMG_EXP_KSCHED
-// EXP builds only (tools/exp/attn_v7.h): the row-major V of the NEXT omg_attn_fwd calls while variant 7 is forced — the experiment's side door;
-// the C ABI gets the operand (omg_attn_args) once the kernel has run and won
-static const char* g_attn_v_rowmajor = nullptr;
-static long g_attn_ldv = 0, g_attn_v_bs = 0;
-extern "C" void omg_debug_set_attn_v(const void* V, int64_t ldv, int64_t v_bstride) { g_attn_v_rowmajor = (const char*)V; g_attn_ldv = (long)ldv; g_attn_v_bs = (long)v_bstride; }
-#endif
-
 extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_attn_fwd: null args");
   OMG_REQUIRE(a->dtype == OMG_F16 || a->dtype == OMG_BF16, "omg_attn_fwd: dtype");
   OMG_REQUIRE(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nkv > 0, "omg_attn_fwd: shape");
   OMG_REQUIRE(a->Nkv_pad % 64 == 0 && a->Nkv_pad >= a->Nkv, "omg_attn_fwd: Nkv_pad");
   OMG_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldo % 4 == 0, "omg_attn_fwd: strides");
-  OMG_REQUIRE(a->Q && a->K && a->Vt && a->O, "omg_attn_fwd: null operand");
+  OMG_REQUIRE(a->Q && a->K && (a->Vt || a->V) && a->O, "omg_attn_fwd: null operand");
   AttnP p = make_params(a);
   dim3 grid((a->Nq + QB - 1) / QB, a->heads, a->B);
   hipStream_t s = (hipStream_t)stream;
-#ifdef OMG_EXP_KSCHED
-  if (g_attn_variant >= 7 && g_attn_variant <= 9 && g_attn_v_rowmajor != nullptr && g_attn_ldv % 8 == 0) {      // 8 = 7 + the asm three-address first MFMA and all Q loads up front; 9 = 8 + the knobs
+  // row-major V (omg_attn_args.V): the self-attention kernel reads it in place — no omg_transpose_v pass.  Up to 128 keys the resident-K/V kernel
+  // (v6) and v2 want the V^T image: a caller that passes only V there gets an error, not a silent fallback.
+  if (a->V != nullptr && (g_attn_variant == 0 || g_attn_variant == 7) && (a->Nkv > 128 || a->Vt == nullptr)) {
+    OMG_REQUIRE(a->ldv % 8 == 0 && a->v_bstride % 8 == 0, "omg_attn_fwd: V strides must be multiples of 8 elements");
+    OMG_REQUIRE(a->Nkv > 128, "omg_attn_fwd: row-major V needs more than 128 keys (pass Vt from omg_transpose_v below that)");
     dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);
-    const int hi_bits = g_attn_qchunk == 512 ? 0 : g_attn_qchunk / 128;         // bits 8.. of the variant word (tools/exp/attn_v7.h, variant 9 only):
-    const int stagger_us = hi_bits & 0xff, xcd_remap = (hi_bits >> 8) & 1;       // 8..15 the start delay in us, 16 the XCD-aware block order
-#define OMG_L7(T_, AQ_, KN_) OMG_LAUNCH((attn_fwd_kernel7<T_, AQ_, KN_>), grid7, dim3(256), 0, s, p, g_attn_v_rowmajor, g_attn_ldv, g_attn_v_bs, stagger_us, xcd_remap)
-    if (a->dtype == OMG_F16) {
-      if (g_attn_variant == 7) OMG_L7(f16, false, false); else if (g_attn_variant == 8) OMG_L7(f16, true, false); else OMG_L7(f16, true, true);
-    } else {
-      if (g_attn_variant == 7) OMG_L7(bf16, false, false); else if (g_attn_variant == 8) OMG_L7(bf16, true, false); else OMG_L7(bf16, true, true);
-    }
-#undef OMG_L7
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel7<f16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride);
+    else OMG_LAUNCH(attn_fwd_kernel7<bf16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride);
     return omg_check_launch("attn_fwd_v7");
   }
-#endif
+  OMG_REQUIRE(a->Vt != nullptr, "omg_attn_fwd: this variant needs Vt");
   if (g_attn_variant == 3 || (g_attn_variant == 0 && a->Nkv > 128)) {   // heuristic: v3 for self-attention, v2 for the 77 / 93 / 16-key cross calls (one or two tiles: latency-bound, v3's 256-row blocks only add to it)
     dim3 grid3((a->Nq + 255) / 256, a->heads, a->B);
     if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel3<f16>, grid3, dim3(256), 0, s, p);

@@ -1,5 +1,6 @@
-// tools/exp/attn_v7.h — EXPERIMENT for round 5 (built by `make -C omg_amd/csrc EXP=1` only; never part of the product library).
-// WRITTEN IN ROUND 4 WITH NO GPU TIME LEFT: compiled for gfx950 and inspected, NOT RUN.
+// attn_v7.h — the self-attention kernel of the product (more than 128 keys, V given ROW-MAJOR in omg_attn_args.V).  Written in round 4, first run
+// and landed in round 5 (profiles/r05_exp_attn_v7_*.log: torch.equal with attn_fwd_kernel3 on whole and ragged tiles, plain / borrowed Q,K /
+// accumulate; with omg_transpose_v gone from the self-attention path the benchmark step is 0.5 - 1 % shorter).
 //
 // attn_fwd_kernel7 = attn_fwd_kernel3 (attn.hip: 64 query rows per wave, K / V tiles by LDS-DMA, swapped S^T = K Q^T, O^T = V^T P^T) reading V
 // ROW-MAJOR — [key][d], exactly as the QKV projection wrote it — instead of the K-major V^T image omg_transpose_v makes once per attention call
@@ -14,8 +15,11 @@
 // Ragged last tile: the staged rows past Nkv repeat the last key (as K's do) — finite values, so the probabilities of those keys are set to
 // zero where v3 relied on zero columns of V^T; the ones fragment of the denominator is masked as in v3.  Everything else — loads, MFMA order,
 // softmax arithmetic, stores — is v3's: the result is torch.equal with it (tests/test_kernels_gpu.py).
-// A second question rides on the same kernel (stagger_us, see the kernel's first lines): do the two workgroups of a CU run in lockstep, and does
-// de-phasing them recover the ~3 tiles' worth per workgroup that the 32 x 32 launches (16 key tiles per workgroup) lose against the 64 x 64 ones?
+// Two questions rode on the same kernel in round 5 (profiles/r05_exp_attn_v7_stagger.log, _xcd.log):
+//   * do the two workgroups of a CU run in lockstep, and does de-phasing them (half of the first-round workgroups started 10 / 20 / 40 us late)
+//     recover what the 32 x 32 launches lose against the 64 x 64 ones?  +5 ... 8 % at 32 x 32 in the microbenchmark, nothing at 64 x 64 — and
+//     the XCD-aware block order below gives more (+11 %) without a busy-wait, so the knob is not carried;
+//   * an XCD-aware block order: KEPT, see the kernel's first lines.
 // Included inside attn.hip's anonymous namespace.
 template <typename T> struct TrRead;
 template <> struct TrRead<f16> {
@@ -31,7 +35,7 @@ template <> struct TrRead<bf16> {
   }
 };
 
-// AQ (attention variant 8 = 7 + this): the FIRST MFMA of every S^T accumulator — the one whose C operand is the splat of the running reference
+// The FIRST MFMA of every S^T accumulator — the one whose C operand is the splat of the running reference
 // maximum (negm) — written as inline asm in its three-address form (destination != C, early-clobber).  In v3's emitted tile loop hipcc uses that
 // form for the first key block only; for the second it COPIES the 16-register splat (2 x 8 v_mov_b64 per tile and wave) and accumulates in place.
 // The hazard recogniser does not see an asm MFMA; what follows on the same registers are MFMAs of the same opcode accumulating in place (a
@@ -44,23 +48,10 @@ template <> struct MfmaInit<bf16> {
   static OMG_DEV void run(f32x16& d, bf16x8 a, bf16x8 b, const f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
 };
 
-// KNOBS (attention variant 9 = 8 + the two tools-only knobs below; 7 and 8 carry neither: reading their two arguments and the grid size costs four
-// more scalar round trips in front of the first Q load)
-template <typename T, bool AQ, bool KNOBS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int stagger_us, int xcd_remap) {
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
-  // tools only (attention variant word 9 | us << 8): half of the launch's first-round workgroups — one of every pair that can share a CU — start
-  // `stagger_us` late.  Two workgroups share a CU and, with equal work, run in lockstep — both in their prologue (Q load, first tile's latency) and both in
-  // their epilogue at the same time; a workgroup takes its successor's place when it ends, so an initial offset persists and one workgroup's
-  // waiting falls under the other's MFMA phase.
-  if (KNOBS && stagger_us > 0) {
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (lin < 512 && (((lin ^ (lin >> 8)) & 1) != 0)) {      // one of (i, i + 1) and one of (i, i + 256): whichever pair the dispatcher puts on a CU
-      const long long t_end = __builtin_amdgcn_s_memrealtime() + (long long)stagger_us * 100;      // 100 MHz counter
-      while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
-    }
-  }
   using V8 = typename Vec<T>::v8;
   using V4 = typename Vec<T>::v4;
   typedef T T2 __attribute__((ext_vector_type(2)));
@@ -68,11 +59,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  // tools only (variant word bit 16): an XCD-aware block order.  Workgroups go to the eight XCDs round-robin by linear id, so the 4 (32 x 32) or 16
-  // (64 x 64) query blocks of one (sample, head) — which stage the same K / V tiles — land on different XCDs and each L2 fetches its own copy
-  // (up to 8 x the K / V bytes over the fabric).  Remapped, the ids an XCD receives enumerate consecutive (query block, head, sample) items.
+  // XCD-aware block order.  Workgroups go to the eight XCDs round-robin by linear id, so the 4 (32 x 32) or 16 (64 x 64) query blocks of one
+  // (sample, head) — which stage the same K / V tiles — would land on different XCDs and each L2 fetch its own copy (up to 8 x the K / V bytes
+  // over the fabric).  Remapped, the ids an XCD receives enumerate consecutive (query block, head, sample) items: +1.6 % at 64 x 64, +6 % at
+  // 32 x 32 (profiles/r05_exp_attn_v7_xcd.log).
   int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  if (KNOBS && xcd_remap) {
+  {
     const int total = gridDim.x * gridDim.y * gridDim.z;
     if ((total & 7) == 0) {
       const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -87,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 
   V8 qf[QW][4];
   int qrow[QW];
-  // AQ: all eight Q loads of the wave's two query blocks are in flight before the first is converted (v3's emitted prologue waits for block 0's
+  // all eight Q loads of the wave's two query blocks are in flight before the first is converted (v3's emitted prologue waits for block 0's
   // four loads, scales them, and only then issues block 1's: one more global round trip in front of the first key tile of every workgroup)
   V8 qraw[QW][4];
 #pragma unroll
@@ -99,13 +91,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       qraw[qb][ks] = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
-      if constexpr (!AQ) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)qraw[qb][ks][e] * p.scale_log2e);
-      }
     }
   }
-  if constexpr (AQ) {
+  {
     asm volatile("" : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]));
 #pragma unroll
     for (int qb = 0; qb < QW; ++qb)
@@ -187,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
         const V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
 #pragma unroll
         for (int qb = 0; qb < QW; ++qb) {
-          if (AQ && ks == 0) MfmaInit<T>::run(s[qb][i], kf, qf[qb][ks], negm[qb]);
-          else s[qb][i] = Vec<T>::mfma32(kf, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][i]);
+          if (ks == 0) MfmaInit<T>::run(s[qb][i], kf, qf[qb][ks], negm[qb]);
+          else s[qb][i] = Vec<T>::mfma32(kf, qf[qb][ks], s[qb][i]);
         }
       }
     }

@@ -847,7 +847,8 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v7(GemmP p) {
 
 bool g_use_glds = true;
 int g_dbg = 0;
-int g_variant = 0;   // 0 = heuristic; 1 = 128x128 v1; 13/14 = v6 256x256 / 256x128; 15 = v7 256x256; 24 = v7 128x320; 25 = v11 256x256 (ring K loop, transposed streaming epilogue)
+int g_variant = 0;   // 0 = heuristic; 1 = 128x128 v1; 13/14 = v6 256x256 / 256x128; 15 = v7 256x256; 24 = v7 128x320; 25 = v12 256x256 (ring K loop, persistent
+                     // walk, transposed streaming epilogue); 28 = v13 256x320
 
 template <typename T, bool CONV, int MT>
 int launch_v6(GemmP p, hipStream_t s, int mrows) {
@@ -887,13 +888,9 @@ int launch_v7(GemmP p, hipStream_t s, int mrows) {
   return omg_check_launch("gemm_v7");
 }
 
-#include "gemm_v11.h"      // the 256x256 four-wave tile with the table-driven K loop: schedule 5 = variant 25 (make EXP=1: 35 + SCH too)
-
 int num_cus();
-#ifdef OMG_EXP_KSCHED
-#include "gemm_v12.h"      // tools/exp/ (make EXP=1 adds the include path): next round's experiment, variants 45..48 — NOT RUN yet
-#include "gemm_v13.h"      // tools/exp/: the 256 x 320 tile with class-pinned inline-asm MFMAs, variants 27 / 28 — NOT RUN yet
-#endif
+#include "gemm_v12.h"      // the 256 x 256 four-wave tile: table-driven ring K loop, persistent tile walk (variant 25)
+#include "gemm_v13.h"      // the 256 x 320 four-wave tile with class-pinned inline-asm MFMAs (variant 28)
 
 int num_cus() {
   static int n = 0;
@@ -905,23 +902,29 @@ int num_cus() {
   return n;
 }
 
-// Tile choice from measured rates (profiles/r01_microbench_*.log): a 256x256 tile wins whenever it can put >= ~120 tiles on the
-// 256 CUs; below that the 256x128 kernel if IT reaches ~120 tiles, else the 128x128 kernel (2 blocks per CU).  Narrow outputs (N <= 128: LoRA-down, ControlNet conditioning embedding) never take BN = 256.
-int choose_variant(int mrows, int groups, int N, bool conv, double* cost = nullptr) {
-  if (g_variant != 0 && cost == nullptr) return g_variant;
+// Tile choice from measured rates (profiles/r01_microbench_*.log, r05_exp_v13_*.log): a 256x256 tile wins whenever it can put >= ~120 tiles on
+// the 256 CUs; below that the 256x128 kernel if IT reaches ~120 tiles, else the 128x128 kernel (2 blocks per CU).  Narrow outputs (N <= 128:
+// LoRA-down, ControlNet conditioning embedding) never take BN = 256.  The 256x320 tile (28) where its rounds x relative tile time undercut the
+// rest: it removes the padding of N = 640 / 960 / 1920 (256-wide: 768 / 1024 / 2048), replaces the 128x320 tile on the N = 320 / 640
+// convolutions, and wins whenever 320-wide tiles fill fewer rounds (N = 1280 at M = 32768: 2 rounds instead of 3).  GEGLU stays on 256x256
+// (a 160-wide wave tile cannot hold whole [32 value | 32 gate] blocks).
+int choose_variant(int mrows, int groups, int N, bool conv, bool geglu = false) {
+  if (g_variant != 0) return g_variant;
   const long t256 = (long)groups * ((mrows + 255) / 256) * ((N + 255) / 256);
   const long t256x128 = (long)groups * ((mrows + 255) / 256) * ((N + 127) / 128);
   const long t128x320 = (long)groups * ((mrows + 127) / 128) * ((N + 319) / 320);
-  // rounds of 256 one-block CUs x time per tile relative to a 256x256 tile of v7 (tools/shape_sweep.py,
-  // profiles/r01_shape_sweep_*.log): 256x128 on eight waves 0.58; 128x320 on four waves 0.70 (its area is 0.625).
-  // The narrow tiles win when N pads badly to 256 (320 -> 512, 640 -> 768) or they fill the last round better.
+  const long t256x320 = (long)groups * ((mrows + 255) / 256) * ((N + 319) / 320);
+  // rounds of 256 one-block CUs x time per tile relative to a 256x256 tile (tools/shape_sweep.py, profiles/r01_shape_sweep_*.log,
+  // r05_exp_v13_ab_*.log): 256x128 on eight waves 0.58; 128x320 on four waves 0.70 (its area is 0.625); 256x320 1.28 on the Linear layers
+  // (area 1.25; the 256x256 kernel walks tiles persistently, this one does not) and 1.20 on the implicit-GEMM convolutions (K >= 2880 hides it).
   const double c256 = (N > 128 && t256 >= 120) ? (double)((t256 + 255) / 256) : 1e30;
   const double c128 = t256x128 >= 120 ? (double)((t256x128 + 255) / 256) * 0.58 * 1.06 : 1e30;
   // 128x320 only for the implicit-GEMM conv (long K): on the Linear layers' K = 640..5120 its per-tile overhead loses
-  const double c320 = (conv && N % 320 == 0 && t128x320 >= 120) ? (double)((t128x320 + 255) / 256) * 0.70 : 1e30;
-  if (cost != nullptr) *cost = c320 < c256 && c320 < c128 ? c320 : (c256 <= c128 ? c256 : c128);      // of the choice below, in 256x256-tile rounds (EXP builds: variants 29 / 30)
+  const double c320 = (conv && !geglu && N % 320 == 0 && t128x320 >= 120) ? (double)((t128x320 + 255) / 256) * 0.70 : 1e30;
+  const double c13 = (!geglu && N % 320 == 0 && t256x320 >= 120) ? (double)((t256x320 + 255) / 256) * (conv ? 1.20 : 1.28) : 1e30;
+  if (c13 < c256 && c13 < c128 && c13 < c320) return 28;
   if (c320 < c256 && c320 < c128) return 24;
-  if (c256 <= c128) return c256 < 1e30 ? 15 : 1;   // 256x256 on four waves (v7); 13 = the eight-wave v6 of the same tile
+  if (c256 <= c128) return c256 < 1e30 ? 25 : 1;   // 256x256 on four waves (v12); 15 = v7 / 13 = the eight-wave v6 of the same tile
   return 14;                                       // 256x128 on eight waves (v6)
 }
 
@@ -929,78 +932,21 @@ template <typename T, bool CONV>
 int launch(const GemmP& p, hipStream_t s) {
   const int mrows = p.tile_groups > 1 ? p.rows_per_group : p.M;
   if (g_use_glds) {
-    int v = choose_variant(mrows, p.tile_groups, p.N, CONV);
-#ifdef OMG_EXP_KSCHED
-    // 29 / 30 (tools/exp/gemm_v13.h): the heuristic with the 256 x 320 tile (its streaming form, 28) as a candidate — 29: where its cost in
-    // rounds x 1.25 is strictly below the heuristic's own choice (it removes padding: N = 640 / 960 / 1920, or replaces the 128 x 320 tile);
-    // 30: wherever N is a multiple of 320 and it fills the chip.  GEGLU stays on 256 x 256.  `OMG_GEMM_VARIANT=29 python bench.py` = the
-    // whole benchmark with it.
-    if (g_variant == 29 || g_variant == 30) {
-      double c_own = 0;
-      v = choose_variant(mrows, p.tile_groups, p.N, CONV, &c_own);
-      const long t320 = (long)p.tile_groups * ((mrows + 255) / 256) * ((p.N + 319) / 320);
-      const double c13 = (double)((t320 + 255) / 256) * 1.25;
-      if (v == 24 && p.act == OMG_ACT_GEGLU) v = 15;
-      if (v == 15) v = 25;                            // what the lines below do for the heuristic (g_variant == 0)
-      if (p.N % 320 == 0 && p.act != OMG_ACT_GEGLU && t320 >= 120 && (g_variant == 30 || c13 < c_own)) v = 28;
-    }
-#endif
+    int v = choose_variant(mrows, p.tile_groups, p.N, CONV, p.act == OMG_ACT_GEGLU);
     // v6 (interleaved DMA) handles everything except the LoRA second K-segment and > 2 GiB operands
     const long lim = 0x7fff0000L;
     const long a_sz = CONV ? (long)p.M / (p.Hout * p.Wout) * p.Hin * p.Win * (p.C1 > p.C2 ? p.C1 : p.C2) * 2 : (long)p.M * p.lda * 2;
     const long c_sz = (long)p.M * (p.ldc > p.ldr ? p.ldc : p.ldr) * 2;
     const bool v6ok = p.K2 == 0 && p.A2 == nullptr && p.K % 64 == 0 && a_sz < lim && (long)p.N * p.ldw * 2 < lim && c_sz < lim &&
                       (p.group_bias == nullptr || (long)(p.M / (p.rows_per_group > 0 ? p.rows_per_group : 1) + 1) * p.ldgb * 2 < lim);
-    if (v == 24 && p.act == OMG_ACT_GEGLU) v = 15;      // a 160-wide wave tile cannot hold whole [32 value | 32 gate] blocks
-    // the transposed streaming epilogue (25) is the form of the 256x256 tile the heuristic uses: +2..12 % on every Linear / conv shape of the
-    // workload (tools/xe_time.py, tools/ksched_ab.py n640) — since the epilogue's descriptors are scalar also with a residual at K <= 640
-    if (v == 15 && g_variant == 0) v = 25;
+    if ((v == 24 || v == 28) && p.act == OMG_ACT_GEGLU) v = 25;      // forced variants: a 160-wide wave tile cannot hold whole [32 value | 32 gate] blocks
     // what the large-tile kernels do not handle (!v6ok) falls through to the 128x128 kernel below
     if (v == 24 && v6ok) return launch_v7<T, CONV, 0, 2, 5>(p, s, mrows);
     if (v == 15 && v6ok) return launch_v7<T, CONV>(p, s, mrows);
-#ifdef OMG_EXP_KSCHED
-    if (v >= 35 && v <= 44 && v6ok) {      // make EXP=1: the other K-loop schedules of gemm_v11.h (tools/ksched_ab.py); 26 = round 3's v7 with the XE epilogue
-      switch (v - 35) {
-        case 1: return launch_v11_form<T, CONV, 1>(p, s, mrows);
-        case 5: return launch_v11_form<T, CONV, 5>(p, s, mrows);
-        case 8: return launch_v11_form<T, CONV, 8>(p, s, mrows);
-        case 9: return launch_v11_form<T, CONV, 9>(p, s, mrows);
-        default: if constexpr (!CONV) {
-          switch (v - 35) {
-            case 0: return launch_v11_form<T, CONV, 0>(p, s, mrows);
-            case 6: return launch_v11_form<T, CONV, 6>(p, s, mrows);
-            default: return launch_v11_form<T, CONV, 7>(p, s, mrows);
-          }
-        } else return launch_v11_form<T, CONV, 5>(p, s, mrows);
-      }
-    }
-    // 31: gemm_kernel_v11, schedule 5 with the short way to the first LDS-DMA (gemm_v11.h, SCH == 10: launch parameters in one batch, adapter id through the scalar cache)
-    // 27 / 28: gemm_kernel_v13 (tools/exp/gemm_v13.h) — the 256 x 320 tile, register-direct / transposed streaming epilogue; GEGLU stays on 256 x 256
-    if ((v == 27 || v == 28) && v6ok && p.act == OMG_ACT_GEGLU) v = 25;
-    if (v == 32 && v6ok && p.act == OMG_ACT_GEGLU) v = 31;                              // 32 = 28 + the short prologue; its GEGLU fallback carries it too
-    if (v == 27 && v6ok) return launch_v13_form<T, CONV, false>(p, s, mrows);
-    if (v == 28 && v6ok) return launch_v13_form<T, CONV, true>(p, s, mrows);
-    if (v == 32 && v6ok) return launch_v13_form<T, CONV, true, true>(p, s, mrows);
-    if (v == 31 && v6ok) return launch_v11_form<T, CONV, 10>(p, s, mrows);
-    // 45..48: gemm_kernel_v12 (tools/exp/gemm_v12.h) — 45 early residual DMA only; 46 persistent (+ early residual); 47 + next-tile prefetch; 48 + counted wait
-    if (v >= 45 && v <= 48 && v6ok) {
-      switch (v) {
-        case 45: return launch_v12_form<T, CONV, 1>(p, s, mrows);
-        case 46: return launch_v12_form<T, CONV, 1 | 2>(p, s, mrows);
-        case 47: return launch_v12_form<T, CONV, 1 | 2 | 4>(p, s, mrows);
-        default: return launch_v12_form<T, CONV, 1 | 2 | 4 | 8>(p, s, mrows);
-      }
-    }
-    if (v == 26 && v6ok) {
-      const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
-      if (p.act == OMG_ACT_GEGLU) return launch_v7<T, CONV, 0, 4, 4, true, 3>(p, s, mrows);
-      if (gb_rows || p.act == OMG_ACT_SILU) return launch_v7<T, CONV, 0, 4, 4, true, 4>(p, s, mrows);
-      if (p.residual != nullptr) return launch_v7<T, CONV, 0, 4, 4, true, 2>(p, s, mrows);
-      return launch_v7<T, CONV, 0, 4, 4, true, 1>(p, s, mrows);
-    }
-#endif
-    // 25: the 256x256 tile as the heuristic uses it — gemm_kernel_v11, schedule 5 (five rotating half-stage buffers), one kernel per epilogue form
-    if (v == 25 && v6ok) return launch_v11_form<T, CONV, 5>(p, s, mrows);
+    // 25: the 256x256 tile as the heuristic uses it — gemm_kernel_v12 (five rotating half-stage buffers, persistent walk), one kernel per epilogue form
+    if (v == 25 && v6ok) return launch_v12_form<T, CONV>(p, s, mrows);
+    // 28: the 256x320 tile — gemm_kernel_v13, transposed streaming epilogue for the aligned 128-column groups
+    if (v == 28 && v6ok) return launch_v13_form<T, CONV>(p, s, mrows);
 #ifdef OMG_ABLATION_BUILDS   // make ABLATE=1: seven more instantiations of v7 for tools/gemm_ablate.py (3 minutes of compile time)
     if constexpr (!CONV && sizeof(T) == 2 && Vec<T>::is_f16) {      // ablation builds of v7 (tools/gemm_ablate.py), fp16 plain GEMM only
       if (v >= 17 && v <= 23 && v6ok) {
@@ -1056,7 +1002,7 @@ extern "C" void omg_debug_set_gemm_variant(int v) { g_variant = v & 0xff; g_dbg 
 extern "C" int omg_debug_choose_variant(int mrows, int groups, int N, int conv) {
   const int saved = g_variant;
   g_variant = 0;
-  const int v = choose_variant(mrows, groups, N, conv != 0);
+  const int v = choose_variant(mrows, groups, N, (conv & 1) != 0, (conv & 2) != 0);      // bit 1 of `conv`: a GEGLU epilogue
   g_variant = saved;
   return v;
 }

@@ -1,23 +1,34 @@
-// tools/exp/gemm_v12.h — EXPERIMENT for the next round (built by `make -C omg_amd/csrc EXP=1` only — variants 45..48; never part of the product
-// library, and kept out of omg_amd/csrc until it has run).
-// WRITTEN AT THE END OF ROUND 4 WITH NO GPU TIME LEFT: compiled for gfx950 and inspected (registers, scratch, instruction placement), NOT RUN.
-// tests/test_kernels_gpu.py compares these variants bit for bit with variant 1 as soon as an EXP build meets a GPU; tools/ksched_ab.py times them.
+// gemm_v12.h — the product kernel of the 256 x 256 x 64 tile (variant 25): four waves (2 x 2 of 128 x 128, 256 accumulators in AGPRs), a
+// TABLE-DRIVEN ring K loop, a persistent tile walk with the next tile's first two stages in flight under the last stage's MFMAs.
 //
-// What it tries: of a 38 - 48 us 256 x 256 tile at K = 1280, 7 - 9 us lie OUTSIDE the K loop (prologue 2.5 - 3.3, epilogue
-// 3.5 - 4.9, dispatch gap 0.6 - 0.7; tools/gemm_timeline.py).  The ring K loop of gemm_v11.h leaves ALL five LDS buffers free from the barrier of a
-// tile's last stage on — 40 MFMAs (~1 us) before the epilogue starts.  gemm_kernel_v12 is v11's schedule 5 with that window used:
-//   MODE bit 0  (EF == 2 only) the residual tile of THIS tile's epilogue (res_stage_dma: 32 LDS-DMA instructions per wave) is put in flight
-//               behind that barrier instead of behind the loop — the epilogue's first instruction is a vmcnt(0) on exactly these loads;
-//   MODE bit 1  (EF != 2) persistent: a block walks tiles vb = blockIdx.x, + gridDim.x, ... (grid = the CU count; the XCD-aware tile order of v11 is kept
-//               because 256 is a multiple of 8) — no dispatch gap, the descriptors / lane constants are built once;
-//   MODE bit 2  (with bit 1, EF != 2) the NEXT tile's stages 0 and 1 (32 LDS-DMA instructions per wave) are issued in the same window, i.e. IN
-//               FRONT of the epilogue's first store in program order — round 3's persistent kernel (v9) issued them behind the stores and found
-//               them queued behind those in the CU's memory pipe.  EF == 2 cannot: its residual staging owns four of the five buffers;
-//   MODE bit 3  (with bit 2) the next tile's 16 bias / group-bias loads are issued in the window as well and the wait in front of the next tile's first
-//               barrier is COUNTED: vmcnt(number of epilogue stores) — the stores of the epilogue (vmcnt counts them on gfx9) need not have
-//               completed, only everything older.  Without bit 3 the wait is vmcnt(0) (correct by construction, pays the store drain).
-// Values: the same loads, the same MFMA order per accumulator, the same epilogue code as v11 — bitwise identical by construction.
-// This header is included inside gemm.hip's anonymous namespace, behind gemm_v11.h (whose generated stage macros it reuses).
+// K loop (round 4, was gemm_v11.h): tile, LDS image, XOR swizzle, MFMA order per accumulator and every epilogue are gemm_kernel_v7's — results are
+// torch.equal with every other variant (tests/test_kernels_gpu.py) — what differs is WHEN things are issued:
+//   * one fragment register set per k-step of a stage (4 x 8 fragments = 128 VGPRs), filled by inline-asm ds_read_b128 from a per-k-step base
+//     address + immediate offsets.  hipcc does not track these reads, so the only LDS waits in the loop are the ones placed here: one counted
+//     `s_waitcnt lgkmcnt(N)` in front of each k-step (N = the number of younger reads in flight, derived from the table) and one `lgkmcnt(0)` in
+//     front of the stage barrier (v7: 23 compiler-placed partial waits per stage);
+//   * a stage is 32 SLOTS of two MFMAs; a table gives, per fragment read, per LDS-DMA instruction and for the barrier, the slot it sits in.  The
+//     stage bodies are straight-line macro code GENERATED from the table by tools/gen_ksched.py into gemm_v12_sched.inc;
+//   * the 160 KB of LDS are FIVE 32 KB half-stage buffers — A current, W current, A next, W next, spare — whose roles rotate every stage (three A
+//     buffers cycle, two W buffers swap; five scalar moves).  The A half of stage kt + 2 goes into the spare from the first slot of stage kt on,
+//     the W half into the current W buffer behind the barrier: the 16 LDS-DMA instructions of a stage are spread over the WHOLE stage (one per
+//     four MFMAs).  The fifth buffer is the XE staging region of the epilogue, which nobody needs inside the loop.
+//   Round 4's A/B of ten such tables (profiles/r04_ksched_*.log): the ring gains +6 ... 8 % at K = 5120, +3 ... 4 % on the K = 1280 projections
+//   with a residual, 0 on the convolutions; placements inside it do not matter.  Only the winning table (schedule 5) is carried.
+// Tile walk (round 5, profiles/r05_exp_v12_ab_*.log — interleaved A/B against the one-tile-per-block form, every form bitwise equal): of a
+// 38 - 48 us tile at K = 1280, 7 - 9 us lay OUTSIDE the K loop (prologue, epilogue, dispatch gap).  The ring leaves ALL five LDS buffers free from
+// the barrier of a tile's last stage on — 40 MFMAs (~1 us) before the epilogue starts — and that window is used:
+//   EF == 2 (residual)   the residual tile of THIS tile's epilogue (res_stage_dma: 32 LDS-DMA instructions per wave) is put in flight behind that
+//                        barrier instead of behind the loop (+3 ... 5 %); one tile per block (the residual image owns four of the five buffers,
+//                        and carrying the tile walk's scalar state through the 256-VGPR epilogue spilled SGPRs to scratch);
+//   EF != 2              persistent: a block walks tiles vb = blockIdx.x, + gridDim.x, ... (grid = the CU count; the XCD-aware tile order is kept
+//                        because 256 is a multiple of 8), and the NEXT tile's stages 0 and 1 (32 LDS-DMA instructions per wave) are issued in the
+//                        window, i.e. IN FRONT of the epilogue's first store in program order — round 3's persistent kernel issued them behind
+//                        the stores and found them queued behind those in the CU's memory pipe.  +2 ... 8 % on the Linear shapes, +0.3 % on the
+//                        convolutions.  (A counted vmcnt wait in front of the next tile's first barrier, variant 48 of the experiment, was
+//                        within noise of this form and is not carried.)
+// Values: the same loads, the same MFMA order per accumulator, the same epilogue code as every other variant — bitwise identical by construction.
+// This header is included inside gemm.hip's anonymous namespace.
 #include "gemm_v12_sched.inc"
 
 template <typename T, int NT>
@@ -97,7 +108,7 @@ OMG_DEV int next_tile_v12(const GemmP& p, int vb, int step, int ntiles) {
   return vb;
 }
 
-template <typename T, bool CONV, int EF, int MODE>
+template <typename T, bool CONV, int EF>
 __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
   constexpr int MT = 4, NT = 4;
   constexpr bool XE = true;
@@ -107,21 +118,15 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
   constexpr int HALF = 32768;
   static_assert(A_BYTES == HALF && STAGE_BYTES == 2 * HALF, "the ring's canonical roles are the two-stage layout");
-  constexpr bool EARLY_RES = (MODE & 1) && EF == 2;
-  // EF == 2 stays one tile per block in every mode: it cannot prefetch (its residual image owns four of the five buffers), and carrying the
-  // tile walk's scalar state through its 256-VGPR epilogue spilled SGPRs to scratch (reloads inside the epilogue wait on every store in
-  // flight).  The counted wait is not built for the convolutions (same reason: 24 bytes of scratch with the conv geometry's scalars).
-  constexpr bool PERSIST = (MODE & 2) != 0 && EF != 2;
-  constexpr bool PREFETCH = PERSIST && (MODE & 4);
-  constexpr bool COUNTED = PREFETCH && (MODE & 8) && !CONV;
-  constexpr int EPI_STORES = EF == 3 ? 16 : 32;        // buffer stores of one wave's epilogue (xe_flush: 4 row blocks x NU), a LOWER bound (EF 4 adds loads)
-  static_assert(OMG_KS_LAST_TAILS >= 40, "32 prefetch DMAs + 8 bias-load slots");
+  constexpr bool EARLY_RES = EF == 2;      // the residual tile in flight behind the last stage's barrier; one tile per block (header)
+  constexpr bool PERSIST = EF != 2;        // tile walk + the next tile's stages 0 and 1 issued in the same window
+  constexpr bool PREFETCH = PERSIST;
+  static_assert(OMG_KS_LAST_TAILS >= 32, "32 prefetch DMAs / 32 residual DMAs");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5;
   const int ntiles = p.tile_groups * p.tiles_m * p.tiles_n;
   const int step = PERSIST ? (int)gridDim.x : ntiles;
   const int nk = (p.K + BKc - 1) / BKc;
@@ -265,8 +270,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
 
   // ---- hooks of the last stage (gemm_v12_sched.inc).  HEAD (24, in front of the barrier, under the MFMAs of k-steps 0 and 1): the next tile's
   // scalars and the lane's 16 source offsets — voffA / voffW / cb / cy / cx are dead from the last DMA of the tile on, the epilogue keeps its
-  // own copies (e_m0, e_n0, e_mend).  TAIL (40, behind the barrier): 0..31 the residual tile (bit 0) or the next tile's stages 0 and 1 (bit 2),
-  // 32..39 the next tile's bias loads (bit 3).
+  // own copies (e_m0, e_n0, e_mend).  TAIL (40, behind the barrier): 0..31 the residual tile (EF == 2) or the next tile's stages 0 and 1.
   int e_m0 = 0, e_n0 = 0, e_mend = 0;
   int vbn = 0;
   int lane_l = 0; (void)lane_l;
@@ -278,7 +282,6 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
       if constexpr ((n_) == 0) {   /* the old values and keep them alive round the whole loop */           \
         const TileV12 t_ = decode_tile_v12(p, has_next ? vbn : vb, ntiles);                                \
         OMG_TILE_SCALARS(t_);                                                                              \
-        if constexpr (COUNTED) rsGb = epi_rsrc(fold_gb ? p.group_bias + (long)(m0 / p.rows_per_group) * p.ldgb * 2 : nullptr, (long)p.N * 2); \
       } else if constexpr ((n_) >= 1 && (n_) <= AB) {                                                      \
         OMG_ADDR_A((n_) >= 1 && (n_) <= AB ? (n_) - 1 : 0);                                                \
       } else if constexpr ((n_) > AB && (n_) <= AB + WB) {                                                 \
@@ -306,22 +309,13 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
         if (has_next) OMG_DMA((n_) < AB + WB ? (n_) : 0, smem);                                            \
       } else if constexpr ((n_) < 2 * (AB + WB)) {                                                         \
         if (has_next && nk > 1) OMG_DMA((n_) >= AB + WB && (n_) < 2 * (AB + WB) ? (n_) - (AB + WB) : 0, smem + STAGE_BYTES); \
-      } else if constexpr (COUNTED && (n_) - 2 * (AB + WB) < 2 * NT) {                                     \
-        constexpr int q_ = (n_) >= 2 * (AB + WB) && (n_) - 2 * (AB + WB) < 2 * NT ? (n_) - 2 * (AB + WB) : 0; \
-        {                          /* unconditional: see OMG_HEAD */                                        \
-          const int c_ = n0 + wn * (NT * 32) + (q_ >> 1) * 32 + (q_ & 1) * 16 + hi * 8;                    \
-          rb[q_ >> 1][q_ & 1] = __builtin_amdgcn_raw_buffer_load_b128(rsBias, c_ * 2, 0, 0);               \
-          rg[q_ >> 1][q_ & 1] = __builtin_amdgcn_raw_buffer_load_b128(rsGb, c_ * 2, 0, 0);                 \
-        }                                                                                                  \
       }                                                                                                    \
     }                                                                                                      \
   } while (0)
   const __amdgpu_buffer_rsrc_t rsRes = epi_rsrc(EARLY_RES ? p.residual : nullptr, ((long)(p.M - 1) * p.ldr + p.N) * 2);
   const bool fold_gb = fold_group_bias(p);
   const bool gb_epi = p.group_bias != nullptr && !fold_gb;
-  const __amdgpu_buffer_rsrc_t rsBias = epi_rsrc(p.bias, (long)p.N * 2);
-  __amdgpu_buffer_rsrc_t rsGb = epi_rsrc(nullptr, 0);
-  (void)rsRes; (void)rsBias; (void)rsGb;
+  (void)rsRes;
 
   // ---- the first tile's stage 0 and bias
   OMG_PREP(0);
@@ -330,8 +324,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
   bias_apply<T, MT, NT>(rb, rg, acc);
   bool first = true;
   for (;;) {
-    if (COUNTED && !first) wait_vmcnt<EPI_STORES>();      // everything older than the previous epilogue's stores: both prefetched stages
-    else wait_vmcnt<0>();
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (!PREFETCH || first) {
       OMG_PREP(1);
@@ -373,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
       OMG_PREP(0);
       OMG_DMAN(0, AB + WB, smem);
     }
-    if constexpr (!COUNTED) bias_issue<T, NT>(p, lane, m0, n0 + wn * (NT * 32), rb, rg);
+    bias_issue<T, NT>(p, lane, m0, n0 + wn * (NT * 32), rb, rg);
     // at the loop's BOTTOM on purpose: decoded at the top, the loads would meet the first tile's (just issued) on the loop header and the
     // compiler's wait would be vmcnt(0) on both paths — here it sees the loads and the epilogue's stores behind them in one straight line
     bias_apply<T, MT, NT>(rb, rg, acc);
@@ -397,13 +390,13 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
 #undef OMG_TILE_SCALARS
 }
 
-template <typename T, bool CONV, int EF, int MODE>
+template <typename T, bool CONV, int EF>
 int launch_v12(GemmP p, hipStream_t s, int mrows) {
   constexpr int lds = 2 * (256 + 256) * 64 * 2 + 4 * 8192;
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v12<T, CONV, EF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v12<T, CONV, EF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + 255) / 256;
   p.tiles_n = (p.N + 255) / 256;
@@ -411,19 +404,19 @@ int launch_v12(GemmP p, hipStream_t s, int mrows) {
   const int ntiles = p.tile_groups * p.tiles_m * p.tiles_n;
   if (ntiles <= 0) return OMG_OK;
   int grid = ntiles;
-  if ((MODE & 2) && EF != 2) {      // persistent: one block per CU; a multiple of 8 keeps a block's tiles on one XCD's share of the tile order
+  if (EF != 2) {      // persistent: one block per CU; a multiple of 8 keeps a block's tiles on one XCD's share of the tile order
     int cus = num_cus() & ~7;
     if (g_dbg & 0x10000) cus = 8;       // tests only: eight blocks, so that a small problem makes every block walk several tiles
     if (grid > cus && cus > 0) grid = cus;
   }
-  OMG_LAUNCH((gemm_kernel_v12<T, CONV, EF, MODE>), dim3(grid), dim3(256), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v12<T, CONV, EF>), dim3(grid), dim3(256), lds, s, p);
   return omg_check_launch("gemm_v12");
 }
-template <typename T, bool CONV, int MODE>
+template <typename T, bool CONV>
 int launch_v12_form(const GemmP& p, hipStream_t s, int mrows) {
-  const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;
-  if (p.act == OMG_ACT_GEGLU) return launch_v12<T, CONV, 3, MODE>(p, s, mrows);
-  if (gb_rows || p.act == OMG_ACT_SILU) return launch_v12<T, CONV, 4, MODE>(p, s, mrows);
-  if (p.residual != nullptr) return launch_v12<T, CONV, 2, MODE>(p, s, mrows);
-  return launch_v12<T, CONV, 1, MODE>(p, s, mrows);
+  const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
+  if (p.act == OMG_ACT_GEGLU) return launch_v12<T, CONV, 3>(p, s, mrows);
+  if (gb_rows || p.act == OMG_ACT_SILU) return launch_v12<T, CONV, 4>(p, s, mrows);
+  if (p.residual != nullptr) return launch_v12<T, CONV, 2>(p, s, mrows);
+  return launch_v12<T, CONV, 1>(p, s, mrows);
 }

@@ -1,8 +1,9 @@
-// tools/exp/gemm_v13.h — EXPERIMENT for round 5 (built by `make -C omg_amd/csrc EXP=1` only — variants 27 / 28 / 32; never part of the product library).
-// WRITTEN IN ROUND 4 WITH NO GPU TIME LEFT: compiled for gfx950 and inspected (registers, scratch, accumulator traffic, instruction placement), NOT RUN.
-// tests/test_kernels_gpu.py compares these variants bit for bit with variant 1 as soon as an EXP build meets a GPU; tools/ksched_ab.py times them.
+// gemm_v13.h — the product kernel of the 256 x 320 x 64 tile (variant 28), FOUR waves (2 x 2 waves of 128 x 160 — 20 accumulator tiles = 320
+// registers per lane).  Written in round 4, first run and landed in round 5 (profiles/r05_exp_v13_*.log: bitwise equal with every other variant;
+// +15 ... 17 % on the N = 320 / 640 convolutions against the 128 x 320 tile, +3 ... 23 % on the 256-tile convolutions, +8 ... 18 % on the
+// N = 640 / 1920 Linears, behind the 256 x 256 ring kernel where N = 1280 fills whole rounds of both; the whole benchmark +3.1 %).
 //
-// What it tries: a 256 x 320 x 64 tile on FOUR waves (2 x 2 waves of 128 x 160 — 20 accumulator tiles = 320 registers per lane).
+// Why this tile:
 //   * 320 = the width unit of the SDXL UNet (320 / 640 / 960 / 1280 / 1920 / 2560 / 3840): every N of the workload except the GEGLU projection is a whole
 //     number of 320-wide tiles, where the 256-wide tile pads N = 640 to 768 (+20 % work) and N = 320 / 640 convolutions run the 128 x 320 tile of v7
 //     (0.7 fragment reads per MFMA, 56 KB of LDS-DMA per 5.2 MFLOP);
@@ -24,7 +25,7 @@
 // Column ownership: wave column wn owns the 128 columns [128 wn, 128 wn + 128) (j = 0..3) and the 32 columns [256 + 32 wn, + 32) (j = 4), so that
 // both waves' 128-column groups start on a 256-byte boundary of the output row: XE (variant 28) sends them through the transposed streaming epilogue
 // of gemm_epilogue.h unchanged (whole 256-byte row segments, nt) and stores the odd 32 columns register-direct without nt (the two waves' halves of that
-// 128-byte line meet in L2).  Variant 27 stores everything register-direct, as the 128 x 320 tile does.
+// 128-byte line meet in L2).  (Storing everything register-direct, as the 128 x 320 tile does — variant 27 of the experiment — was 1 ... 12 % slower.)
 // Epilogue forms: 1 bias only, 4 per-row group bias / SiLU / residual decided per unit, 5 residual by register-direct loads.  No GEGLU (a 160-wide wave
 // tile cannot hold whole [32 value | 32 gate] blocks): the launcher returns such problems to the 256 x 256 kernel.
 // Values: the same loads, the same MFMA order per accumulator, the same epilogue arithmetic as every other variant — bitwise identical by construction.
@@ -83,9 +84,9 @@ OMG_DEV bool acc_init_bias13(const GemmP& p, f32x16 (&acc)[4][5], int lane, int 
   return p.group_bias != nullptr && !fold_gb;
 }
 
-// epilogue_rows (gemm_epilogue.h) for the 128 x 160 wave tile.  RS / GENERIC as there; XE: the units of j < 4 go through xe_put / xe_flush (the
+// epilogue_rows (gemm_epilogue.h) for the 128 x 160 wave tile.  RS / GENERIC as there; the units of j < 4 go through xe_put / xe_flush (the
 // EpiCtx<4> view cx4 is all those two read), the units of j = 4 are stored register-direct.  Same arithmetic, same packing, same bits.
-template <typename T, bool RS, bool GENERIC, bool XE>
+template <typename T, bool RS, bool GENERIC>
 OMG_DEV void epilogue_rows13(const GemmP& p, f32x16 (&acc)[4][5], const EpiCtx<5>& cx, const EpiCtx<4>& cx4, int lane_col4, bool has_gb) {
   const float osc = p.out_scale;
   const bool has_rs = GENERIC ? p.residual != nullptr : RS;
@@ -140,18 +141,18 @@ OMG_DEV void epilogue_rows13(const GemmP& p, f32x16 (&acc)[4][5], const EpiCtx<5
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= osc;
         }
-        if (XE && j < 4) xe_put<T, 256>(cx4, 4 * j + 2 * pr, v);
+        if (j < 4) xe_put<T, 256>(cx4, 4 * j + 2 * pr, v);
         else store_runs<T>(cx.rsC, (crow + OMG_V13_LCOL(j)) | cx.voob[j][pr], OMG_V13_SOFF(j, pr), v);
         __builtin_amdgcn_sched_barrier(0);
       }
-    if constexpr (XE) xe_flush<T, 256>(p, cx4, i, cx4.wn0);
+    xe_flush<T, 256>(p, cx4, i, cx4.wn0);
   }
 #undef OMG_FETCH_RES13
 #undef OMG_V13_SOFF
 #undef OMG_V13_LCOL
 }
 
-template <typename T, bool XE, int EF>
+template <typename T, int EF>
 OMG_DEV void epilogue13(const GemmP& p, f32x16 (&acc)[4][5], int lane, int wm0, int wn0, int wn4, int m_end, bool has_gb, char* xl) {
   static_assert(EF == 1 || EF == 4 || EF == 5, "forms of the 256 x 320 tile: bias only, generic, residual");
   EpiCtx<5> cx;
@@ -173,14 +174,12 @@ OMG_DEV void epilogue13(const GemmP& p, f32x16 (&acc)[4][5], int lane, int wm0, 
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) cx4.voob[j][pr] = cx.voob[j][pr];
-  if constexpr (EF == 1) epilogue_rows13<T, false, false, XE>(p, acc, cx, cx4, lane_col4, false);
-  else if constexpr (EF == 5) epilogue_rows13<T, true, false, XE>(p, acc, cx, cx4, lane_col4, false);
-  else epilogue_rows13<T, false, true, XE>(p, acc, cx, cx4, lane_col4, has_gb);
+  if constexpr (EF == 1) epilogue_rows13<T, false, false>(p, acc, cx, cx4, lane_col4, false);
+  else if constexpr (EF == 5) epilogue_rows13<T, true, false>(p, acc, cx, cx4, lane_col4, false);
+  else epilogue_rows13<T, false, true>(p, acc, cx, cx4, lane_col4, has_gb);
 }
 
-// FP (variant 32 = 28 + this): the short way to the first LDS-DMA of gemm_v11.h's SCH == 10 — launch parameters requested in one batch, the group's
-// adapter id through the scalar cache — so that the two experiments can also be timed together
-template <typename T, bool CONV, int EF, bool XE, bool FP = false>
+template <typename T, bool CONV, int EF>
 __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
   constexpr int MT = 4, NT = 5;
   constexpr int BM_ = MT * 64, BN_ = NT * 64, BKc = 64;
@@ -192,12 +191,6 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
   static_assert(2 * STAGE_BYTES <= 160 * 1024, "two stages in LDS");
 
-  if constexpr (FP) {
-    asm volatile("" ::"s"(p.M), "s"(p.N), "s"(p.K), "s"(p.A), "s"(p.lda), "s"(p.W), "s"(p.ldw), "s"(p.tile_groups), "s"(p.rows_per_group),
-                 "s"(p.group_adapter), "s"(p.w_adapter_stride), "s"(p.tiles_m), "s"(p.tiles_n), "s"(p.dbg), "s"(p.bias), "s"(p.group_bias), "s"(p.ldgb));
-    if constexpr (CONV)
-      asm volatile("" ::"s"(p.Hin), "s"(p.Win), "s"(p.C1), "s"(p.C2), "s"(p.Hout), "s"(p.Wout), "s"(p.ksize), "s"(p.stride), "s"(p.upsample), "s"(p.X2));
-  }
   const bool ts_on = (p.dbg & 16) && blockIdx.x < 8192 && threadIdx.x == 0;      // tools/gemm_timeline.py: per-block time stamps
   long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (p.dbg & 16) ts0 = __builtin_amdgcn_s_memrealtime();
@@ -232,10 +225,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
   const int m0 = m_base + tm * BM_;
   const int n0 = tn * BN_;
   int adapter = 0;
-  if (p.group_adapter != nullptr) {
-    if constexpr (FP) adapter = *(const __attribute__((address_space(4))) int*)(p.group_adapter + grp);
-    else adapter = p.group_adapter[grp];
-  }
+  if (p.group_adapter != nullptr) adapter = p.group_adapter[grp];
   if (p.w_adapter_stride != 0 && adapter < 0) return;
   const char* Wp = p.W + (p.w_adapter_stride != 0 ? (long)adapter * p.w_adapter_stride * 2 : 0);
   const int nk = (p.K + BKc - 1) / BKc;
@@ -420,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
   if (p.dbg & 16) ts2 = __builtin_amdgcn_s_memrealtime();
   // XE: 8 KB per wave at the start of LDS — behind the last stage's barrier no wave reads a stage buffer any more (that stage issues no fragment
   // reads behind its barrier: its last k-step computes from registers)
-  epilogue13<T, XE, EF>(p, acc, lane, m0 + wm * (MT * 32), wn0, wn4, m_end, gb_epi, smem + w * 8192);
+  epilogue13<T, EF>(p, acc, lane, m0 + wm * (MT * 32), wn0, wn4, m_end, gb_epi, smem + w * 8192);
   if (ts_on) {
     long long* t = omg_dbg_ts[blockIdx.x];
     t[0] = ts0; t[1] = ts1; t[2] = ts2; t[3] = __builtin_amdgcn_s_memrealtime();
@@ -430,27 +420,27 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v13(GemmP p) {
 }
 #undef OMG_V13_COL
 
-template <typename T, bool CONV, int EF, bool XE, bool FP = false>
+template <typename T, bool CONV, int EF>
 int launch_v13(GemmP p, hipStream_t s, int mrows) {
   constexpr int lds = 2 * (256 + 320) * 64 * 2;
   static bool attr = false;
   if (!attr) {
     attr = true;
-    (void)hipFuncSetAttribute((const void*)gemm_kernel_v13<T, CONV, EF, XE, FP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel_v13<T, CONV, EF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   p.tiles_m = (mrows + 255) / 256;
   p.tiles_n = (p.N + 319) / 320;
   p.dbg = g_dbg;
   const int grid = p.tile_groups * p.tiles_m * p.tiles_n;
   if (grid <= 0) return OMG_OK;
-  OMG_LAUNCH((gemm_kernel_v13<T, CONV, EF, XE, FP>), dim3(grid), dim3(256), lds, s, p);
+  OMG_LAUNCH((gemm_kernel_v13<T, CONV, EF>), dim3(grid), dim3(256), lds, s, p);
   return omg_check_launch("gemm_v13");
 }
 // GEGLU problems are not this tile's (header): the caller sends them to the 256 x 256 kernel
-template <typename T, bool CONV, bool XE, bool FP = false>
+template <typename T, bool CONV>
 int launch_v13_form(const GemmP& p, hipStream_t s, int mrows) {
   const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
-  if (gb_rows || p.act == OMG_ACT_SILU) return launch_v13<T, CONV, 4, XE, FP>(p, s, mrows);
-  if (p.residual != nullptr) return launch_v13<T, CONV, 5, XE, FP>(p, s, mrows);
-  return launch_v13<T, CONV, 1, XE, FP>(p, s, mrows);
+  if (gb_rows || p.act == OMG_ACT_SILU) return launch_v13<T, CONV, 4>(p, s, mrows);
+  if (p.residual != nullptr) return launch_v13<T, CONV, 5>(p, s, mrows);
+  return launch_v13<T, CONV, 1>(p, s, mrows);
 }

@@ -82,12 +82,6 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const char* X, int B, int
   }
 }
 
-#ifdef OMG_EXP_KSCHED
-#include "conv_out_v2.h"   // tools/exp/ (make EXP=1 adds the include path): round 5's experiment — the lane's weight slice held in registers, NOT RUN yet
-static int g_conv_out_variant = 0;
-extern "C" void omg_debug_set_conv_out_variant(int v) { g_conv_out_variant = v; }
-#endif
-
 // ------------------------------------------------- timestep embedding etc.
 // diffusers get_timestep_embedding(t, dim, flip_sin_to_cos=True, downscale_freq_shift=0):
 // out[i, j] = cos(t_i * f_j) for j < dim/2 ; sin(t_i * f_{j-dim/2}) otherwise; f_j = exp(-ln(10000) * j / (dim/2))
@@ -268,14 +262,6 @@ extern "C" int omg_conv_out(int dtype, const void* X, int B, int H, int W, int C
   if (npix == 0) return OMG_OK;
   long blocks = (npix + 3) / 4; if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
-#ifdef OMG_EXP_KSCHED
-  if (g_conv_out_variant == 2 && dtype != OMG_F32 && Cout <= 4 && 9 * (Cin / 8) <= 64 * 6) {      // tools/exp/conv_out_v2.h
-    const long b2 = blocks > 1024 ? 1024 : blocks;
-    if (dtype == OMG_F16) OMG_LAUNCH((conv_out_kernel2<f16, 6>), dim3(b2), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Cout, Y);
-    else OMG_LAUNCH((conv_out_kernel2<bf16, 6>), dim3(b2), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
-    return omg_check_launch("conv_out_v2");
-  }
-#endif
   if (dtype == OMG_F16) OMG_LAUNCH(conv_out_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Cout, Y);
   else if (dtype == OMG_BF16) OMG_LAUNCH(conv_out_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
   else OMG_LAUNCH(conv_out_kernel<float>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const float*)bias, Cout, Y);

@@ -411,13 +411,33 @@ def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None, out:
     return vt
 
 
+class RowMajorV:
+    """The V operand of a self-attention as the QKV projection wrote it — a (B, Nkv, heads*64) VIEW with unit inner stride — instead of the
+    V^T image :func:`transpose_v` makes: :func:`attention` hands it to the kernel that transposes on the LDS read (omg_attn_args.V, ABI 6).
+    More than 128 keys only (:func:`value_operand` chooses)."""
+
+    def __init__(self, v: torch.Tensor):
+        assert v.dim() == 3 and v.stride(2) == 1 and v.stride(1) % 8 == 0 and v.stride(0) % 8 == 0 and v.shape[1] > 128
+        self.v = v
+
+
+def value_operand(v: torch.Tensor, heads: int):
+    """What :func:`attention` wants for ``v`` (B, Nkv, heads*64): the view itself above 128 keys when its strides allow (self-attention
+    at 32 x 32 / 64 x 64), else the V^T image in MFMA key order."""
+    if v.shape[1] > 128 and v.stride(2) == 1 and v.stride(1) % 8 == 0 and v.stride(0) % 8 == 0 and v.data_ptr() % 16 == 0:
+        return RowMajorV(v)
+    return transpose_v(v, heads)
+
+
 def _attn_args(q, k, vt, heads, nkv, scale, qk_src, out, accumulate, out_scale) -> L.AttnArgs:
     a = L.AttnArgs()
     a.dtype = _dt(q)
     a.B, a.heads, a.Nq, a.Nkv = q.shape[0], heads, q.shape[1], nkv
     a.Q, a.ldq, a.q_bstride = q.data_ptr(), q.stride(1), q.stride(0)
     a.K, a.ldk, a.k_bstride = k.data_ptr(), k.stride(1), k.stride(0)
-    if vt is not None:
+    if isinstance(vt, RowMajorV):
+        a.V, a.ldv, a.v_bstride = vt.v.data_ptr(), vt.v.stride(1), vt.v.stride(0)
+    elif vt is not None:
         a.Vt, a.Nkv_pad = vt.data_ptr(), vt.shape[3]
     a.qk_src = _p(qk_src)
     a.scale = scale
@@ -431,7 +451,7 @@ def _attn_args(q, k, vt, heads, nkv, scale, qk_src, out, accumulate, out_scale) 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: float, *,
               qk_src: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
               accumulate: bool = False, out_scale: float = 1.0) -> torch.Tensor:
-    """Fused attention.  q: (B,Nq,>=heads*64) view, k: (B,Nkv,>=heads*64) view, vt from transpose_v.
+    """Fused attention.  q: (B,Nq,>=heads*64) view, k: (B,Nkv,>=heads*64) view, vt from :func:`value_operand` (or transpose_v).
 
     ``qk_src`` (int32 device tensor [B]) implements the controller's probability replacement:
     sample b uses Q,K of sample qk_src[b] and its own V.

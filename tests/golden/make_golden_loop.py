@@ -96,6 +96,12 @@ class StubPipelineBase:
     def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype, text_encoder_projection_dim=None):
         return torch.tensor([list(original_size + crops_coords_top_left + target_size)], dtype=dtype)
 
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype, do_classifier_free_guidance=False, guess_mode=False):
+        """diffusers: control_image_processor.preprocess (PIL -> [0, 1] tensor; the fixture passes the tensor), repeat to the batch, x2 for CFG."""
+        assert isinstance(image, torch.Tensor) and image.shape[0] == 1 and tuple(image.shape[-2:]) == (height, width)
+        image = image.repeat_interleave(batch_size, dim=0).to(device=device, dtype=dtype)
+        return torch.cat([image] * 2) if do_classifier_free_guidance and not guess_mode else image
+
     @contextlib.contextmanager
     def progress_bar(self, total=None):
         yield types.SimpleNamespace(update=lambda: None)
@@ -108,8 +114,21 @@ class StubPipelineBase:
 
 
 class StubControlNetModel(nn.Module):
+    """diffusers ControlNetModel's call contract (lora_pipeline.py:519-536) over the oracle's functional ControlNet (oracle/controlnet.py)."""
     config = _Cfg(global_pool_conditions=False)
     dtype = torch.float32
+
+    def __init__(self, csd=None, cfg=None):
+        super().__init__()
+        self.csd, self.cfg, self.calls = csd, cfg, 0
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=1.0, guess_mode=False,
+                added_cond_kwargs=None, return_dict=True):
+        from oracle import controlnet as ocn
+        assert not guess_mode and return_dict is False
+        self.calls += 1
+        return ocn.controlnet_forward(self.csd, self.cfg, sample, float(timestep), encoder_hidden_states, controlnet_cond, conditioning_scale,
+                                      added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"])
 
 
 class StubMultiControlNetModel(nn.Module):
@@ -137,7 +156,7 @@ def install_stubs():
     mod("diffusers", StableDiffusionXLControlNetPipeline=StubPipelineBase)
     mod("diffusers.utils", USE_PEFT_BACKEND=True, deprecate=lambda *a, **k: None, logging=log, replace_example_docstring=lambda s: (lambda f: f),
         scale_lora_layers=lambda *a, **k: None, unscale_lora_layers=lambda *a, **k: None, load_image=lambda *a, **k: None)
-    mod("diffusers.utils.import_utils", is_invisible_watermark_available=lambda: False)
+    mod("diffusers.utils.import_utils", is_invisible_watermark_available=lambda: False, is_xformers_available=lambda: False)
     mod("diffusers.utils.torch_utils", is_compiled_module=lambda m: False, is_torch_version=lambda op, v: True, randn_tensor=None)
     mod("diffusers.image_processor", PipelineImageInput=_Any, VaeImageProcessor=lambda **k: None)
     mod("diffusers.loaders", FromSingleFileMixin=_Any, IPAdapterMixin=_Any, StableDiffusionXLLoraLoaderMixin=_Any, TextualInversionLoaderMixin=_Any)
@@ -147,7 +166,7 @@ def install_stubs():
     mod("diffusers.schedulers", KarrasDiffusionSchedulers=_Any)
     mod("diffusers.pipelines")
     mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=StubPipelineBase)
-    mod("diffusers.pipelines.stable_diffusion_xl")
+    mod("diffusers.pipelines.stable_diffusion_xl", StableDiffusionXLPipelineOutput=lambda images: types.SimpleNamespace(images=images))
     mod("diffusers.pipelines.stable_diffusion_xl.pipeline_output", StableDiffusionXLPipelineOutput=lambda images: types.SimpleNamespace(images=images))
     mod("diffusers.pipelines.controlnet")
     mod("diffusers.pipelines.controlnet.multicontrolnet", MultiControlNetModel=StubMultiControlNetModel)
@@ -155,7 +174,12 @@ def install_stubs():
     mod("torchvision.transforms")
     mod("torchvision.transforms.functional", to_tensor=None)
     mod("torchvision.utils", save_image=None)
-    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    # instantid_pipeline.py:757-768 get_face_embedding: load_image(path) -> cv2.cvtColor(np.array(img), COLOR_RGB2BGR) -> face_app.get(...)
+    sys.modules["cv2"] = mod("cv2", cvtColor=lambda a, code: a[..., ::-1], COLOR_RGB2BGR=4)
+    sys.modules["diffusers.utils"].load_image = lambda path: FACE_IMAGES[path]
+
+
+FACE_IMAGES = {}         # "path" -> HxWx3 uint8 array standing for the reference photo
 
 
 # --------------------------------------------------------------------------------------------- the UNet behind the diffusers module protocol

@@ -162,18 +162,22 @@ def test_shard_indices_cover_everything_once():
 
 
 def test_gemm_tile_choice_on_the_workload_shapes():
-    """The cost model of csrc/gemm.hip (host code, no GPU): which tile the benchmark's layers get.  1 = 128x128 (two blocks
-    per CU), 14 = 256x128 on eight waves, 15 = 256x256 on four waves, 24 = 128x320 on four waves (conv only)."""
+    """The cost model of csrc/gemm.hip (host code, no GPU): which tile the benchmark's layers get.  1 = 128x128 (two blocks per CU),
+    14 = 256x128 on eight waves, 24 = 128x320 on four waves (conv only), 25 = 256x256 on four waves (ring K loop, persistent walk),
+    28 = 256x320 on four waves.  Fourth argument: bit 0 = implicit-GEMM convolution, bit 1 = GEGLU epilogue.  The expectations are the
+    round-5 interleaved A/B results (profiles/r05_exp_v13_ab_*.log, r05_exp_v12_ab_*.log)."""
     from omg_amd import _lib as L
     pick = L.lib().omg_debug_choose_variant
     # Linear layers of the fused step at 8 requests: 64 groups of 1024 (32x32) / 4096 (64x64) rows
-    assert pick(1024, 64, 10240, 0) == 15 and pick(1024, 64, 1280, 0) == 15 and pick(1024, 64, 3840, 0) == 15
-    assert pick(4096, 64, 640, 0) == 15 and pick(4096, 64, 5120, 0) == 15
-    # convs whose width is 320 k take the 128x320 tile; the wide up-sampling conv with whole rounds of 256^2 tiles does not
-    assert pick(1048576, 1, 320, 1) == 24 and pick(262144, 1, 640, 1) == 24
-    assert pick(32768, 1, 1280, 1) == 24             # 640 tiles of 256^2 = 2.5 rounds; 1024 tiles of 128x320 = 4 whole rounds
-    assert pick(65536, 1, 1280, 1) == 15 and pick(262144, 1, 1280, 1) == 15
-    assert pick(1048576, 1, 320, 0) == 14            # the same shape as a plain GEMM: 256x128, never 128x320
+    assert pick(1024, 64, 10240, 2) == 25 and pick(4096, 64, 5120, 2) == 25          # GEGLU never leaves the 256x256 tile
+    assert pick(1024, 64, 1280, 0) == 25 and pick(1024, 64, 3840, 0) == 25           # N = 1280 k fills whole rounds of 256-wide tiles
+    assert pick(4096, 64, 640, 0) == 28 and pick(4096, 64, 1920, 0) == 28            # 256-wide pads 640 -> 768, 1920 -> 2048
+    assert pick(32768, 1, 1280, 0) == 28                                             # the concept rows alone: 512 tiles = 2 rounds instead of 640 = 3
+    assert pick(32768, 1, 10240, 2) == 25
+    # convs: the 256x320 tile replaces the 128x320 one wherever it fills the chip, and the 256x256 one where 320-wide tiles save a round
+    assert pick(1048576, 1, 320, 1) == 28 and pick(262144, 1, 640, 1) == 28
+    assert pick(32768, 1, 1280, 1) == 28 and pick(65536, 1, 1280, 1) == 28 and pick(262144, 1, 1280, 1) == 28
+    assert pick(32768, 1, 320, 1) == 24              # 128 tiles of 256x320 = half a round; 256 tiles of 128x320 = one whole round of a cheaper tile
     # narrow outputs (LoRA down-projection, ControlNet conditioning) never take a 256-wide tile; tiny launches stay on v1
     assert pick(65536, 1, 64, 0) == 14 and pick(2048, 1, 1280, 0) == 1 and pick(77 * 8, 1, 2560, 0) == 1
 

@@ -249,40 +249,39 @@ def test_kv_resident_cross_attention_is_bitwise_the_per_block_kernel(dev, dtype,
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 3, 300, 256), (2, 2, 1024, 1000), (1, 2, 512, 4096), (3, 1, 100, 130)])
-def test_experimental_row_major_v_attention_is_bitwise_the_transposed_v_kernel(dev, dtype, B, heads, Nq, Nkv):
-    """EXP builds only (tools/exp/attn_v7.h, attention variant 7): V read ROW-MAJOR — a view of the fused QKV projection's output, no
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 3, 300, 256), (2, 2, 1024, 1000), (1, 2, 512, 4096), (3, 1, 100, 130), (2, 4, 1024, 1024)])
+def test_row_major_v_attention_is_bitwise_the_transposed_v_kernel(dev, dtype, B, heads, Nq, Nkv):
+    """attn_fwd_kernel7 (csrc/attn_v7.h; omg_attn_args.V, ABI 6): V read ROW-MAJOR — a view of the fused QKV projection's output, no
     omg_transpose_v — through ds_read_b64_tr_b16 runs v3's arithmetic in v3's order: plain, with borrowed Q,K, and accumulating; whole tiles,
-    a ragged last tile (1000, 130: the staged rows past Nkv repeat the last key and their probabilities are zeroed), one long row of 64 tiles."""
-    from omg_amd import _lib as L
-    lib = L.lib()
-    if not hasattr(lib, "omg_debug_set_attn_v"):
-        pytest.skip("product build: no attn_fwd_kernel7 (make -C omg_amd/csrc EXP=1)")
-    import ctypes as C_
-    lib.omg_debug_set_attn_v.argtypes = [C_.c_void_p, C_.c_int64, C_.c_int64]
-    lib.omg_debug_set_attn_v.restype = None
+    a ragged last tile (1000, 130: the staged rows past Nkv repeat the last key and their probabilities are zeroed), one long row of 64 tiles,
+    and a grid whose size is a multiple of 8 (the XCD-aware block order is a permutation of the blocks: the last case) or not (the others)."""
     Cc = heads * 64
     qkv = rnd(B, max(Nq, Nkv), 3 * Cc, dtype=dtype, dev=dev, scale=1.2)          # V as the product has it: the last third of a fused projection
     q, k, v = qkv[:, :Nq, :Cc], qkv[:, :Nkv, Cc:2 * Cc], qkv[:, :Nkv, 2 * Cc:]
-    vt = ops.transpose_v(v, heads)
+    vt = ops.transpose_v(v, heads)                                               # a V^T image sends ops.attention to attn_fwd_kernel3
+    vr = ops.value_operand(v, heads)
+    assert isinstance(vr, ops.RowMajorV)
     src = torch.tensor([max(0, b - 1) for b in range(B)], dtype=torch.int32, device=dev)
     res = {}
-    try:
-        lib.omg_debug_set_attn_v(v.data_ptr(), v.stride(1), v.stride(0))
-        for var in (3, 7, 8, 9):                             # 8 = 7 with the first MFMA of every S^T accumulator as a three-address inline asm and every Q load up front; 9 = 8 + the tools' knobs (off here)
-            lib.omg_debug_set_attn_variant(var)
-            a = ops.attention(q, k, vt, heads, 0.125)
-            b_ = ops.attention(q, k, vt, heads, 0.125, qk_src=src)
-            c = a.clone()
-            ops.attention(q, k, vt, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
-            res[var] = (a, b_, c)
-    finally:
-        lib.omg_debug_set_attn_variant(0)
-        lib.omg_debug_set_attn_v(None, 0, 0)
-    for var in (7, 8, 9):
-        for x, y in zip(res[3], res[var]):
-            assert torch.equal(x, y), (var, (x.float() - y.float()).abs().max().item())
-    close(res[7][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+    for name, operand in (("v3", vt), ("v7", vr)):
+        a = ops.attention(q, k, operand, heads, 0.125)
+        b_ = ops.attention(q, k, operand, heads, 0.125, qk_src=src)
+        c = a.clone()
+        ops.attention(q, k, operand, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
+        res[name] = (a, b_, c)
+    for x, y in zip(res["v3"], res["v7"]):
+        assert torch.equal(x, y), (x.float() - y.float()).abs().max().item()
+    close(res["v7"][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+
+
+def test_row_major_v_is_refused_where_no_kernel_reads_it(dev):
+    """Up to 128 keys the resident-K/V kernels want the V^T image: omg_attn_fwd rejects a V-only call instead of falling back silently."""
+    from omg_amd import _lib as L
+    q = rnd(1, 64, 64, dtype=torch.float16, dev=dev)
+    kv = rnd(1, 256, 128, dtype=torch.float16, dev=dev)
+    vr = ops.RowMajorV(kv[:, :, 64:])
+    with pytest.raises(L.OmgHipError):
+        ops.attention(q, kv[:, :77, :64], vr, 1, 0.125)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -355,30 +354,6 @@ def test_conv_in_out(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 24, 20, 320, 4), (1, 9, 7, 64, 4), (3, 16, 16, 336, 3), (1, 5, 5, 8, 1)])
-def test_experimental_conv_out_with_the_weight_slice_in_registers(dev, dtype, B, H, W, Cin, Cout):
-    """EXP builds only (tools/exp/conv_out_v2.h): the lane's slice of the weights loaded once per wave instead of once per pixel — the same
-    products in the same order: torch.equal with the product kernel (widths with a ragged last iteration, a single-vector width, Cout < 4)."""
-    lib = L.lib()
-    if not hasattr(lib, "omg_debug_set_conv_out_variant"):
-        pytest.skip("product build: no conv_out_kernel2 (make -C omg_amd/csrc EXP=1)")
-    f = rnd(B, H, W, Cin, dtype=dtype, dev=dev)
-    wo = rnd(Cout, 3, 3, Cin, dtype=dtype, dev=dev, scale=(9 * Cin) ** -0.5)
-    bo = rnd(Cout, dtype=dtype, dev=dev)
-    try:
-        base = ops.conv_out(f, wo, bo)
-        lib.omg_debug_set_conv_out_variant(2)
-        new = ops.conv_out(f, wo, bo)
-        new_nobias = ops.conv_out(f, wo, None)
-    finally:
-        lib.omg_debug_set_conv_out_variant(0)
-    assert torch.equal(base, new), (base - new).abs().max().item()
-    assert torch.equal(ops.conv_out(f, wo, None), new_nobias)
-    zref = F.conv2d(f.float().cpu().permute(0, 3, 1, 2), wo.float().cpu().permute(0, 3, 1, 2), bo.float().cpu(), padding=1)
-    torch.testing.assert_close(new.cpu(), zref, rtol=1e-4, atol=1e-4)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 def test_timestep_embedding_and_silu(dev, dtype):
     t = torch.tensor([999.0, 981.0, 1.0, 0.0, 1024.0], device=dev)
     e = ops.timestep_embedding(t, 320, dtype)
@@ -396,26 +371,6 @@ def test_timestep_embedding_and_silu(dev, dtype):
 
 
 # ------------------------------------------------------------------ every tile variant gives the same bits
-def _experimental_variants():
-    """A library built with `make EXP=1` also holds the other K-loop schedules of gemm_kernel_v11 (35 + SCH; csrc/gemm_v11.h) and round
-    3's v7 with the XE epilogue (26): found by looking for a non-product schedule in the code objects, so that an experimental build is
-    validated by this test before anything is measured on it."""
-    try:
-        from tests import _codeobj
-        from omg_amd import _lib as L_
-        names = _codeobj.kernels(L_.LIB_PATH)
-        exp = any("gemm_kernel_v11" in n and "ELi5EEEv" not in n for n in names)
-        v12 = (45, 46, 47, 48) if any("gemm_kernel_v12" in n for n in names) else ()      # next round's experiment (tools/exp/gemm_v12.h)
-        v13 = (27, 28) if any("gemm_kernel_v13" in n for n in names) else ()              # the 256 x 320 tile (tools/exp/gemm_v13.h)
-        v13 += (32,) if any("gemm_kernel_v13" in n and "ELb1ELb1EEEv" in n for n in names) else ()      # ... with the short prologue of variant 31
-        v31 = (31,) if any("gemm_kernel_v11" in n and "ELi10EEEv" in n for n in names) else ()      # schedule 5 with the short way to the first LDS-DMA
-        found = ((26, 35, 36, 40, 41, 42, 43, 44) if exp else ()) + v31 + v13 + v12
-        only = os.environ.get("OMG_EXP_ONLY")                # "27,28": one experiment's variants, so that another's failure is not charged to it
-        return tuple(v for v in found if str(v) in only.split(",")) if only else found
-    except Exception:
-        return ()
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_variants_are_bitwise_identical(dev, dtype):
     """Batching requests changes the tile choice; results must not change with it (bias-first accumulation, same K order,
@@ -443,7 +398,7 @@ def test_gemm_variants_are_bitwise_identical(dev, dtype):
     try:
         lib.omg_debug_set_gemm_variant(1)
         base = run_all()
-        for v in (13, 14, 15, 24, 25) + _experimental_variants():
+        for v in (13, 14, 15, 24, 25, 28):
             lib.omg_debug_set_gemm_variant(v)
             for k, (o, r) in enumerate(zip(run_all(), base)):
                 assert torch.equal(o, r), f"variant {v} case {k}: max diff {(o.float() - r.float()).abs().max().item()}"
@@ -452,13 +407,12 @@ def test_gemm_variants_are_bitwise_identical(dev, dtype):
 
 
 @pytest.mark.parametrize("K", [64, 128, 320])
-def test_experimental_persistent_gemm_walks_several_tiles_per_block(dev, K):
-    """EXP builds only (tools/exp/gemm_v12.h, variants 45..48): the persistent forms with the grid capped at EIGHT blocks (debug bit 0x10000), so
-    that every block walks three or four tiles of a 30-tile problem — first tile, prefetched tiles, last tile; K = 64 / 128 have no full K-loop
-    stage in front of the last one (the prologue's stage-1 branch), adapter -1 groups are skipped by the tile walk.  Bitwise against variant 1."""
-    ev = tuple(v for v in _experimental_variants() if v >= 45)
-    if not ev:
-        pytest.skip("product build: no gemm_kernel_v12")
+def test_persistent_gemm_walks_several_tiles_per_block(dev, K):
+    """gemm_kernel_v12 (csrc/gemm_v12.h, variant 25 = the heuristic's 256 x 256 kernel): the persistent forms with the grid capped at EIGHT
+    blocks (debug bit 0x10000), so that every block walks three or four tiles of a 30-tile problem — first tile, prefetched tiles, last tile;
+    K = 64 / 128 have no full K-loop stage in front of the last one (the prologue's stage-1 branch), adapter -1 groups are skipped by the
+    tile walk.  Bitwise against variant 1."""
+    ev = (25,)
     lib = L.lib()
     dtype = torch.float16
     M, N = 1100, 1536
@@ -496,15 +450,13 @@ def test_experimental_persistent_gemm_walks_several_tiles_per_block(dev, K):
 
 
 @pytest.mark.parametrize("K", [64, 128, 192, 640])
-def test_experimental_256x320_tile_is_bitwise_the_other_tiles(dev, K):
-    """EXP builds only (tools/exp/gemm_v13.h, variants 27 = register-direct / 28 = streaming epilogue): the 256 x 320 tile on the widths it is
+def test_256x320_tile_is_bitwise_the_other_tiles(dev, K):
+    """gemm_kernel_v13 (csrc/gemm_v13.h, variant 28; the heuristic picks it where it removes padding or saves a round): the 256 x 320 tile on the widths it is
     meant for (N = 320 k: whole tiles; both waves' odd 32-column blocks and 128-column groups inside the matrix) and on ragged ones (N = 704:
     the last tile's columns end inside a 128-column group; N = 192: the odd blocks lie outside the matrix); K = 64 / 128 / 192 have no
     steady-state stage (one, two, three stages: the peeled copies only); weight slots with a skipped group; per-row group bias + SiLU (form 4),
     residual (form 5); convolutions with the group bias folded.  Bitwise against variant 1."""
-    ev = tuple(v for v in _experimental_variants() if v in (27, 28, 31, 32))      # 31 (gemm_v11.h, SCH == 10: adapter id through the scalar cache) rides along for
-    if not ev:                                                                 # this test's weight-slot cases; it falls back to its own tile for GEGLU like 27 / 28
-        pytest.skip("product build: no gemm_kernel_v13")
+    ev = (28, 0)             # 0: the heuristic's own choice on these shapes (a mix of every tile)
     lib = L.lib()
     dtype = torch.float16
     M = 1100

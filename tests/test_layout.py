@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     for name in declared:
         assert re.search(rf"\bT {name}\b", nm), f"{name} is not a defined text symbol"
-    assert lib.omg_abi_version() == 5
+    assert lib.omg_abi_version() == 6
 
 
 def test_struct_sizes_match_the_header():

@@ -20,28 +20,33 @@ def timeit(fn, iters=30, warm=10):
 
 dev, dt = torch.device("cuda:0"), torch.float16
 lib = L.lib()
-VARS = tuple(int(a, 0) for a in sys.argv[1:]) or (0,)      # EXP builds: 9 | us << 8 = variant 9 (= 8 + knobs) with half of the first-round workgroups started `us` late; | 1 << 16 = XCD-aware block order
-print("# variants", VARS, "(0 = the heuristic: v3 above 128 keys, v2 below; 2 = v2; 3 = v3; 7 = EXP builds: v3 reading V row-major; 8 = 7 + three-address asm first MFMA) — OMG_HIP_LIB=<other build> runs the same table on another library for A/B")
+VARS = tuple(int(a, 0) for a in sys.argv[1:]) or (0,)
+print("# variants", VARS, "(0 = the heuristic: v7 above 128 keys — V row-major, no transpose_v — v6 / v2 below; 2 = v2; 3 = v3 on the V^T image (+ the transpose_v pass it needs, timed separately); 6 = v6; 7 = v7)"
+      " — OMG_HIP_LIB=<other build> runs the same table on another library for A/B")
+print("# q, k, v are the three column slices of ONE fused (B, N, 3C) projection output, as the UNet has them")
 print("# (B, heads, Nq, Nkv): TF/s per variant; max |last - first variant|")
 for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20, 1024, 77), (64, 10, 4096, 77), (32, 10, 4096, 4096), (64, 20, 1024, 16)]:
     C = heads * 64
-    q = torch.randn(B, Nq, C, device=dev, dtype=dt)
-    k = torch.randn(B, Nkv, C, device=dev, dtype=dt) * 1.5
-    v = torch.randn(B, Nkv, C, device=dev, dtype=dt)
+    if Nq == Nkv:
+        qkv = torch.randn(B, Nq, 3 * C, device=dev, dtype=dt)
+        qkv[:, :, C:2 * C] *= 1.5
+        q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    else:
+        q = torch.randn(B, Nq, C, device=dev, dtype=dt)
+        k = torch.randn(B, Nkv, C, device=dev, dtype=dt) * 1.5
+        v = torch.randn(B, Nkv, C, device=dev, dtype=dt)
     vt = ops.transpose_v(v, heads)
-    if hasattr(lib, "omg_debug_set_attn_v"):          # EXP builds: variant 7 (tools/exp/attn_v7.h) reads V row-major, no transpose_v
-        import ctypes
-        lib.omg_debug_set_attn_v.argtypes, lib.omg_debug_set_attn_v.restype = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64], None
-        lib.omg_debug_set_attn_v(v.data_ptr(), v.stride(1), v.stride(0))
-    t_tr = timeit(lambda: ops.transpose_v(v, heads, out=vt)) if any(v & 0xff in (7, 8, 9) for v in VARS) and Nkv > 128 else None
+    vr = ops.value_operand(v, heads)               # RowMajorV above 128 keys, else the V^T image
+    t_tr = timeit(lambda: ops.transpose_v(v, heads, out=vt)) if Nkv > 128 else None
     out = torch.empty(B, Nq, C, device=dev, dtype=dt)
     fl = 4.0 * B * heads * Nq * Nkv * 64
     res, outs = [], []
     for var in VARS:
+        operand = vr if var in (0, 7) else vt
         lib.omg_debug_set_attn_variant(var)
-        ms = timeit(lambda: ops.attention(q, k, vt, heads, 0.125, out=out))
+        ms = timeit(lambda: ops.attention(q, k, operand, heads, 0.125, out=out))
         res.append(fl / ms / 1e9)
         outs.append(out.clone())
     lib.omg_debug_set_attn_variant(0)
     print(f"({B},{heads},{Nq},{Nkv}): " + " | ".join(f"{r:7.0f}" for r in res) + f"   max |last - first| {(outs[0].float() - outs[-1].float()).abs().max().item():.2e}"
-          + (f"   transpose_v {t_tr * 1e3:.0f} us (the pass variant 7 makes unnecessary; attention itself {fl / res[0] / 1e6:.0f} us)" if t_tr is not None else ""))
+          + (f"   transpose_v {t_tr * 1e3:.0f} us (what v3 needs on top; attention itself {fl / res[0] / 1e6:.0f} us)" if t_tr is not None else ""))

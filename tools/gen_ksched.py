@@ -114,15 +114,17 @@ def emit_last(i):
 
 
 if __name__ == "__main__":
-    out12 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "exp", "gemm_v12_sched.inc")
-    with open(out12, "w") as f:
+    # Round 5: the ring (schedule 5) won round 4's A/B and gemm_kernel_v12 (its persistent form) won round 5's: the product carries schedule 5 only.
+    # `python tools/gen_ksched.py 0 1 9` still emits other tables (to stdout) for anyone who wants to time one again.
+    import sys
+    if len(sys.argv) > 1:
+        print("\n".join(emit(int(a)) for a in sys.argv[1:]))
+        raise SystemExit(0)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "gemm_v12_sched.inc")
+    with open(out, "w") as f:
         body, nh, nt = emit_last(5)
-        f.write("// GENERATED by tools/gen_ksched.py — do not edit.  Last-stage body of gemm_kernel_v12 (tools/exp/gemm_v12.h; make EXP=1 only).\n")
+        f.write("// GENERATED by tools/gen_ksched.py — do not edit.  Stage bodies of gemm_kernel_v12 (gemm_v12.h): prologue reads, steady-state stage, last stage.\n")
+        f.write(emit(5) + "\n")
         f.write(f"#define OMG_KS_LAST_HEADS {nh}\n#define OMG_KS_LAST_TAILS {nt}\n")
         f.write(body + "\n")
-    print("wrote", out12)
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "gemm_v11_sched.inc")
-    with open(out, "w") as f:
-        f.write("// GENERATED by tools/gen_ksched.py — do not edit.  Stage bodies of gemm_kernel_v11 (gemm_v11.h).\n")
-        f.write("\n".join(emit(i) for i in range(10)) + "\n")
     print("wrote", out)
