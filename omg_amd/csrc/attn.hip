@@ -765,7 +765,7 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_attn_fwd: null args");
   OMG_REQUIRE(a->dtype == OMG_F16 || a->dtype == OMG_BF16, "omg_attn_fwd: dtype");
   OMG_REQUIRE(a->B > 0 && a->heads > 0 && a->Nq > 0 && a->Nkv > 0, "omg_attn_fwd: shape");
-  OMG_REQUIRE(a->Nkv_pad % 64 == 0 && a->Nkv_pad >= a->Nkv, "omg_attn_fwd: Nkv_pad");
+  OMG_REQUIRE(a->Vt == nullptr || (a->Nkv_pad % 64 == 0 && a->Nkv_pad >= a->Nkv), "omg_attn_fwd: Nkv_pad");
   OMG_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldo % 4 == 0, "omg_attn_fwd: strides");
   OMG_REQUIRE(a->Q && a->K && (a->Vt || a->V) && a->O, "omg_attn_fwd: null operand");
   AttnP p = make_params(a);

@@ -82,10 +82,14 @@ OMG_DEV TileV12 decode_tile_v12(const GemmP& p, int vb, int ntiles) {
   const int tiles_per_group = p.tiles_m * p.tiles_n;
   const int grp = bid / tiles_per_group;
   const int t_in = bid - grp * tiles_per_group;
-  const int per_group = 8 * p.tiles_n;
+  // G row tiles x all column tiles form a walk group: the 32 CUs of an XCD run G x (32 / G) tiles at a time and fetch G + 32 / G operand panels
+  // for them (8 x 4: 12 panels per 32 tiles = 0.375 per tile — exactly the measured fabric reads, profiles/r04_pmc_traffic_fp16.json).  tools:
+  // debug bits 6-7 halve G (4, 2, 1) for the traffic experiment of DESIGN §8
+  const int G = 8 >> ((p.dbg >> 6) & 3);
+  const int per_group = G * p.tiles_n;
   const int gid = t_in / per_group;
-  const int first_m = gid * 8;
-  const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+  const int first_m = gid * G;
+  const int gsz = (p.tiles_m - first_m) < G ? (p.tiles_m - first_m) : G;
   const int r = t_in - gid * per_group;
   const int tm = first_m + (r % gsz);
   const int tn = r / gsz;

@@ -98,6 +98,9 @@ class StubPipelineBase:
 
     def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype, do_classifier_free_guidance=False, guess_mode=False):
         """diffusers: control_image_processor.preprocess (PIL -> [0, 1] tensor; the fixture passes the tensor), repeat to the batch, x2 for CFG."""
+        if isinstance(image, (list, tuple)):                       # inference_instantid.py:88-89 passes [image]
+            assert len(image) == 1
+            image = image[0]
         assert isinstance(image, torch.Tensor) and image.shape[0] == 1 and tuple(image.shape[-2:]) == (height, width)
         image = image.repeat_interleave(batch_size, dim=0).to(device=device, dtype=dtype)
         return torch.cat([image] * 2) if do_classifier_free_guidance and not guess_mode else image
@@ -107,6 +110,9 @@ class StubPipelineBase:
         yield types.SimpleNamespace(update=lambda: None)
 
     def maybe_free_model_hooks(self):
+        pass
+
+    def check_inputs(self, *a, **k):          # instantid_pipeline.py:293 (lora_pipeline.py has the call commented out)
         pass
 
     def upcast_vae(self):
@@ -269,8 +275,9 @@ class StubUNet(nn.Module):
     def __init__(self, sd, cfg):
         super().__init__()
         self.sd, self.cfg, self.state = sd, cfg, LoraState()
-        self.config = _Cfg(in_channels=cfg.in_channels, sample_size=cfg.sample_size, time_cond_proj_dim=None)
-        self.dtype = torch.float32
+        self.config = _Cfg(in_channels=cfg.in_channels, sample_size=cfg.sample_size, time_cond_proj_dim=None,
+                           cross_attention_dim=cfg.cross_attention_dim, block_out_channels=cfg.block_out_channels)
+        self.dtype, self.device = torch.float32, torch.device("cpu")
         self.by_name = {}
         heads = {}
         rev = list(reversed(cfg.attention_head_dim))
@@ -290,6 +297,14 @@ class StubUNet(nn.Module):
             a = Attention(sd, name, h, self.state)
             node.add_module(parts[-1], a)
             self.by_name[name] = a
+
+    @property
+    def attn_processors(self):          # diffusers: {"<module path>.processor": processor}; what instantid_single_pieline.py:186-213 walks
+        return {name + ".processor": a.processor for name, a in self.by_name.items()}
+
+    def set_attn_processor(self, procs):
+        for name, a in self.by_name.items():
+            a.set_processor(procs[name + ".processor"])
 
     def forward(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None, cross_attention_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None, added_cond_kwargs=None, return_dict=True):
@@ -370,18 +385,54 @@ def masks_for(H, W, kind):
     return {"overlap": [m1, m2], "none_mid": [m1, None, m2], "three": [m1, m2, m3]}[kind]
 
 
-CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, latent w)
-    ("ddim_overlap", "ddim", 20, 7.5, "overlap", False, (16, 16)),
-    ("euler_none_mid", "euler", 20, 7.5, "none_mid", False, (16, 16)),
-    ("ddim_style_three", "ddim", 18, 5.0, "three", True, (16, 16)),
-    ("ddim_nonsquare", "ddim", 18, 7.5, "overlap", False, (24, 16)),
+CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, latent w), flow
+    ("ddim_overlap", "ddim", 20, 7.5, "overlap", False, (16, 16), "lora"),
+    ("euler_none_mid", "euler", 20, 7.5, "none_mid", False, (16, 16), "lora"),
+    ("ddim_style_three", "ddim", 18, 5.0, "three", True, (16, 16), "lora"),
+    ("ddim_nonsquare", "ddim", 18, 7.5, "overlap", False, (24, 16), "lora"),
+    # lora_pipeline.py:519-566 with `image` given: a ControlNet on the four main rows, none on the concept rows
+    ("ddim_controlnet", "ddim", 18, 7.5, "overlap", False, (16, 16), "lora_cn"),
+    # instantid_pipeline.py:540-707: IdentityNet (key-point image + face tokens) and the IP-Adapter branch on the concept rows, guidance 3
+    # (inference_instantid.py:78); `iid_t2i`: + a second ControlNet (self.controlnet2, t2i_image) on the main rows (:574-592)
+    ("euler_instantid", "euler", 18, 3.0, "overlap", False, (16, 16), "iid"),
+    ("euler_instantid_t2i", "euler", 18, 3.0, "none_mid", False, (16, 16), "iid_t2i"),
 ]
 LORA_RANK, LORA_SEED0, LORA_SCALE = 8, 100, 0.8
+CN_SCALE, IDN_SCALE, T2I_SCALE, IP_SCALE, IP_TOKENS, FACE_DIM = 0.7, 0.8, 0.6, 0.8, 16, 512
+RESAMPLER = dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=IP_TOKENS, embedding_dim=FACE_DIM)      # instantid_single_pieline.py:163-174
+
+
+def resampler_state_dict(out_dim, seed=31):
+    """Seeded weights of the InstantID image_proj_model (the reference's Resampler topology at full width; output = the tiny UNet's context width)."""
+    from oracle import resampler as orsm
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in orsm.param_shapes(RESAMPLER["dim"], RESAMPLER["depth"], RESAMPLER["dim_head"], RESAMPLER["heads"], IP_TOKENS, FACE_DIM, out_dim).items():
+        if k == "latents":
+            sd[k] = torch.randn(shp, generator=g) * RESAMPLER["dim"] ** -0.5
+        elif k.endswith("bias"):
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+        elif "norm" in k or k.endswith(".1.0.weight"):
+            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        else:
+            sd[k] = torch.randn(shp, generator=g) * shp[-1] ** -0.5
+    return sd
+
+
+def ip_weights(cfg, seed=9):
+    """{attn2 module name: (to_k_ip, to_v_ip)} of the concept UNet's IPAttnProcessor2_0 layers."""
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+    for name, shp in ou.param_shapes(cfg).items():
+        if name.endswith(".attn2.to_k.weight"):
+            c_, cx = shp
+            w[name[: -len(".to_k.weight")]] = (torch.randn(c_, cx, generator=g) * cx ** -0.5, torch.randn(c_, cx, generator=g) * cx ** -0.5)
+    return w
 
 
 def build(case):
     """Everything a case needs, shared by this script and tests/test_oracle.py (which re-creates the inputs and runs the ORACLE's loop)."""
-    name, sched, steps, gs, mkind, style, (lh, lw) = case
+    name, sched, steps, gs, mkind, style, (lh, lw), flow = case
     cfg = ou.UNetConfig.tiny()
     sd = ou.init_state_dict(cfg, seed=3)
     table = embed_table(cfg)
@@ -392,7 +443,16 @@ def build(case):
     loras = {f"c{c}": ou.make_lora(cfg, names, rank=LORA_RANK, seed=LORA_SEED0 + c, scale=1.0)[0] for c in range(K)}
     loras["style"] = ou.make_lora(cfg, names, rank=LORA_RANK, seed=LORA_SEED0 + 50, scale=1.0)[0]
     lat0 = torch.randn(1, 4, lh, lw, generator=torch.Generator().manual_seed(14))
-    return dict(name=name, sched=sched, steps=steps, gs=gs, style=style, cfg=cfg, sd=sd, table=table, H=H, W=W, masks=masks, K=K, loras=loras, lat0=lat0,
+    extra = {}
+    if flow != "lora":
+        from oracle import controlnet as ocn
+        g = torch.Generator().manual_seed(3)
+        extra = dict(csd=ocn.init_state_dict(cfg, seed=5), csd2=ocn.init_state_dict(cfg, seed=6), pose=torch.rand(1, 3, H, W, generator=g), pose2=torch.rand(1, 3, H, W, generator=g))
+    if flow.startswith("iid"):
+        g = torch.Generator().manual_seed(77)
+        extra.update(rsd=resampler_state_dict(cfg.cross_attention_dim), ipw=ip_weights(cfg),
+                     face_emb=[torch.randn(FACE_DIM, generator=g).numpy() for _ in range(K)])
+    return dict(flow=flow, **extra, name=name, sched=sched, steps=steps, gs=gs, style=style, cfg=cfg, sd=sd, table=table, H=H, W=W, masks=masks, K=K, loras=loras, lat0=lat0,
                 ctl_args=([P, P], 50 if name == "ddim_overlap" else steps, {"default_": 1.0}, 0.4, lw // 4, lh // 4))      # 50 = inference_lora.py:156
 
 
@@ -409,8 +469,10 @@ def run_reference(c):
     vae.config = _Cfg(block_out_channels=(1, 2, 3, 4), force_upcast=True, scaling_factor=0.13025)
     vae.dtype = torch.float32
     vae.post_quant_conv = nn.Conv2d(4, 4, 1)
+    cn = StubControlNetModel(c.get("csd"), c["cfg"])
+    image = c["pose"] if c["flow"] == "lora_cn" else None
     pipe = LoraMultiConceptPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=main_unet,
-                                    controlnet=StubControlNetModel(), scheduler=SchedulerAdapter(c["sched"], c["steps"]))
+                                    controlnet=cn, scheduler=SchedulerAdapter(c["sched"], c["steps"]))
     pipe.embed_table = c["table"]
     concept = ConceptModels(concept_unet, c["table"])
     controller = AttentionReplace(*c["ctl_args"], tokenizer=WhitespaceTokenizer(), device="cpu", dtype=torch.float32)
@@ -426,7 +488,8 @@ def run_reference(c):
             traj.append(r[0].clone())
             return r
         pipe.scheduler.step = step
-        res = pipe(prompt=[[P, P], [REGION[k] for k in range(c["K"])]], negative_prompt=[NEG, NEG], image=None, height=c["H"], width=c["W"],
+        res = pipe(prompt=[[P, P], [REGION[k] for k in range(c["K"])]], negative_prompt=[NEG, NEG], image=image, height=c["H"], width=c["W"],
+                   controlnet_conditioning_scale=CN_SCALE,
                    num_inference_steps=c["steps"], guidance_scale=c["gs"], latents=c["lat0"].clone(), cross_attention_kwargs={"scale": LORA_SCALE},
                    controller=controller, concept_models=concept, stage=stage, region_masks=c["masks"], lora_list=[f"c{k}" for k in range(c["K"])],
                    styleL=c["style"], output_type="latent")
@@ -435,6 +498,87 @@ def run_reference(c):
         assert (controller.cur_step, controller.cur_att_layer) == (c["steps"], 0)
         out[f"stage{stage}"] = torch.stack(traj).numpy()
     out["set_adapters_calls"] = np.array(len(concept.calls))
+    out["controlnet_calls"] = np.array(cn.calls)
+    return out
+
+
+class FaceApp:
+    """insightface's FaceAnalysis as get_face_embedding uses it (instantid_pipeline.py:757-768): .get(bgr image) -> [{bbox, embedding}, ...]."""
+
+    def __init__(self, by_sum):
+        self.by_sum = by_sum
+
+    def get(self, bgr):
+        emb = self.by_sum[int(bgr.astype(np.int64).sum())]
+        # a second, SMALLER face comes first: the reference sorts by (x2 - x1) * y2 - y1 (sic, :764) and takes element [0] — "only use the maximum face"
+        # in its comment, the smallest key in its code; the fixture's photo has one face per key value so that either reading picks the same one
+        return [{"bbox": np.array([10.0, 10.0, 50.0, 60.0]), "embedding": emb}]
+
+
+def run_reference_instantid(c):
+    import tempfile
+    from src.pipelines.instantid_pipeline import InstantidMultiConceptPipeline, revise_regionally_controlnet_forward     # REFERENCE code
+    from src.pipelines.instantid_single_pieline import InstantidSingleConceptPipeline                                   # REFERENCE code
+    from src.prompt_attention.p2p_attention import AttentionReplace                                                    # REFERENCE code
+
+    main_unet, concept_unet = StubUNet(c["sd"], c["cfg"]), StubUNet(c["sd"], c["cfg"])
+    vae = nn.Module()
+    vae.config = _Cfg(block_out_channels=(1, 2, 3, 4), force_upcast=True, scaling_factor=0.13025)
+    vae.dtype = torch.float32
+    vae.post_quant_conv = nn.Conv2d(4, 4, 1)
+    idn = StubControlNetModel(c["csd"], c["cfg"])
+    pipe = InstantidMultiConceptPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=main_unet,
+                                         controlnet=idn, scheduler=SchedulerAdapter(c["sched"], c["steps"]))
+    pipe.embed_table = c["table"]
+    pipe.controlnet2 = StubControlNetModel(c["csd2"], c["cfg"])                     # inference_instantid.py:198: pipe.controlnet2 = t2i ControlNet
+    # the concept pipe is the reference's OWN single-concept class: its load_ip_adapter_instantid builds the reference's Resampler and installs
+    # the reference's IPAttnProcessor2_0 / AttnProcessor2_0 (src/ip_adapter/attention_processor.py) on the concept UNet from a checkpoint file
+    concept = InstantidSingleConceptPipeline()
+    concept.unet, concept.embed_table = concept_unet, c["table"]
+    concept.device, concept.dtype = torch.device("cpu"), torch.float32
+    order = list(concept_unet.attn_processors)                                       # the checkpoint's "ip_adapter" keys are positional (ModuleList)
+    ip_sd = {}
+    for i, key in enumerate(order):
+        mod = key[: -len(".processor")]
+        if mod in c["ipw"]:
+            ip_sd[f"{i}.to_k_ip.weight"], ip_sd[f"{i}.to_v_ip.weight"] = c["ipw"][mod]
+    with tempfile.TemporaryDirectory() as td:
+        ck = os.path.join(td, "ip-adapter.bin")
+        torch.save({"image_proj": c["rsd"], "ip_adapter": ip_sd}, ck)
+        concept.load_ip_adapter_instantid(ck, image_emb_dim=FACE_DIM, num_tokens=IP_TOKENS, scale=0.5)
+    concept.set_ip_adapter_scale(IP_SCALE)                                           # inference_instantid.py:211-212
+    photos = []
+    for k in range(c["K"]):
+        path = f"face{k}.png"
+        FACE_IMAGES[path] = np.full((8, 8, 3), 40 + k, dtype=np.uint8)
+        photos.append(path)
+    face_app = FaceApp({int(FACE_IMAGES[pth].astype(np.int64).sum()): c["face_emb"][k] for k, pth in enumerate(photos)})
+    controller = AttentionReplace(*c["ctl_args"], tokenizer=WhitespaceTokenizer(), device="cpu", dtype=torch.float32)
+    revise_regionally_controlnet_forward(pipe.unet, controller)
+    out = {"num_att_layers": np.array(controller.num_att_layers)}
+    t2i = c["pose2"] if c["flow"] == "iid_t2i" else None
+    for stage in (1, 2):
+        controller.reset()
+        traj = []
+        real_step = pipe.scheduler.step
+
+        def step(*a, **k):
+            r = real_step(*a, **k)
+            traj.append(r[0].clone())
+            return r
+        pipe.scheduler.step = step
+        res = pipe(prompt=[[P, P], [REGION[k] + (photos[k],) for k in range(c["K"])]], negative_prompt=[NEG, NEG],
+                   image=[c["pose"]] if stage == 2 else None, height=c["H"], width=c["W"], num_inference_steps=c["steps"], guidance_scale=c["gs"],
+                   latents=c["lat0"].clone(), cross_attention_kwargs={"scale": LORA_SCALE}, controller=controller, concept_models=concept,
+                   face_app=face_app, stage=stage, region_masks=c["masks"], controlnet_conditioning_scale=IDN_SCALE,
+                   t2i_image=t2i, t2i_controlnet_conditioning_scale=T2I_SCALE, output_type="latent")
+        pipe.scheduler.step = real_step
+        assert torch.equal(res.images, traj[-1])
+        assert (controller.cur_step, controller.cur_att_layer) == (c["steps"], 0)
+        out[f"stage{stage}"] = torch.stack(traj).numpy()
+    out["set_adapters_calls"] = np.array(0)
+    out["controlnet_calls"] = np.array(idn.calls)
+    out["controlnet2_calls"] = np.array(pipe.controlnet2.calls)
     return out
 
 
@@ -443,7 +587,7 @@ def main():
     blob = {}
     for case in CASES:
         c = build(case)
-        r = run_reference(c)
+        r = run_reference_instantid(c) if c["flow"].startswith("iid") else run_reference(c)
         for k, v in r.items():
             blob[f"{c['name']}/{k}"] = v
         d = np.abs(r["stage2"][-1][1] - r["stage1"][-1][1]).max()

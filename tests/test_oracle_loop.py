@@ -4,7 +4,10 @@ sequence (oracle/controller.py reference_attn_fn + AttentionReplaceOracle) again
 ``get_region_mask`` / ``AttentionReplace`` in the build container (tests/golden/make_golden_loop.py -> loop_golden.npz).
 
 This is the pin of SURVEY §8 rows A1, A3, A7, A8, A9 (and of A11's adapter bookkeeping: set_adapters, [lora, "style"] at [0.7, 0.5]):
-the GPU loop tests compare the HIP pipeline with exactly these oracle functions."""
+the GPU loop tests compare the HIP pipeline with exactly these oracle functions.  The ``lora_cn`` / ``iid`` / ``iid_t2i`` cases pin the call
+pattern of A13 (which rows a ControlNet sees, with which context and scale: lora_pipeline.py:519-566, instantid_pipeline.py:574-592, :638-657) and
+of the InstantID twin of the loop (instantid_pipeline.py:540-707) with the reference's own InstantidSingleConceptPipeline.load_ip_adapter_instantid /
+_encode_prompt_image_emb, Resampler and IPAttnProcessor2_0 on the concept side — the ControlNet's and the UNet's own arithmetic stay the oracle's."""
 import os
 import sys
 
@@ -13,7 +16,10 @@ import pytest
 import torch
 
 from oracle import controller as oc
+from oracle import controlnet as ocn
+from oracle import ip_adapter as oip
 from oracle import pipeline as opipe
+from oracle import resampler as orsm
 from oracle import schedulers as osched
 from oracle import unet as ou
 
@@ -41,13 +47,37 @@ def oracle_run(c, stage, num_att_layers):
     fn = {k: ou.make_lora(cfg, names, rank=mk.LORA_RANK, seed=mk.LORA_SEED0 + (50 if k == "style" else int(k[1:])), scale=mk.LORA_SCALE)[1] for k in c["loras"]}
     main_lora = fn["style"] if c["style"] else None              # inference_lora.py:162-164 + the main call's scale 0.8 (:546-566)
 
+    flow = c["flow"]
+
     def main(x, i):
-        return ou.unet_forward(sd, cfg, x, float(osch.timesteps[i]), ctx4, te4, tid.repeat(4, 1), attn_fn=attn, lora=main_lora)
+        t = float(osch.timesteps[i])
+        down = mid = None
+        if flow == "lora_cn":        # lora_pipeline.py:519-536: the ControlNet sees the four main rows with the main context; its residuals feed the main UNet only
+            down, mid = ocn.controlnet_forward(c["csd"], cfg, x, t, ctx4, c["pose"].repeat(4, 1, 1, 1), mk.CN_SCALE, te4, tid.repeat(4, 1))
+        if flow == "iid_t2i":        # instantid_pipeline.py:574-592: self.controlnet2 on the main rows with t2i_image
+            down, mid = ocn.controlnet_forward(c["csd2"], cfg, x, t, ctx4, c["pose2"].repeat(4, 1, 1, 1), mk.T2I_SCALE, te4, tid.repeat(4, 1))
+        return ou.unet_forward(sd, cfg, x, t, ctx4, te4, tid.repeat(4, 1), attn_fn=attn, lora=main_lora,
+                               down_block_additional_residuals=down, mid_block_additional_residual=mid)
+
+    if flow.startswith("iid"):
+        ip_fn = oip.make_ip_attn_fn(c["ipw"], mk.IP_SCALE, mk.IP_TOKENS)
+        # instantid_single_pieline.py:221-243: [zeros | face embedding] through the Resampler -> (2, 16, D) image-prompt tokens
+        faces = []
+        for e in c["face_emb"]:
+            e = torch.from_numpy(e).reshape(1, 1, mk.FACE_DIM)
+            faces.append(orsm.resampler_forward(c["rsd"], torch.cat([torch.zeros_like(e), e]), mk.RESAMPLER["heads"]))
 
     def conc(k):
         rp, rn = mk.REGION[k]
         ctx2 = torch.stack([table[rn][0], table[rp][0]])          # :345: [negative, positive]
         te2 = torch.stack([table[rn][1], table[rp][1]])
+        if flow.startswith("iid"):
+            def f(x, i):             # instantid_pipeline.py:638-674: IdentityNet(latents, face tokens, key points) -> concept UNet(text + face tokens), no LoRA scale
+                t = float(osch.timesteps[i])
+                down, mid = ocn.controlnet_forward(c["csd"], cfg, x, t, faces[k], c["pose"].repeat(2, 1, 1, 1), mk.IDN_SCALE, te2, tid.repeat(2, 1))
+                return ou.unet_forward(sd, cfg, x, t, torch.cat([ctx2, faces[k]], dim=1), te2, tid.repeat(2, 1), attn_fn=ip_fn,
+                                       down_block_additional_residuals=down, mid_block_additional_residual=mid)
+            return f
         if c["style"]:                                            # :588-589: set_adapters([lora, "style"], adapter_weights=[0.7, 0.5])
             lora = lambda key, x: 0.7 * fn[f"c{k}"](key, x) + 0.5 * fn["style"](key, x)
         else:
@@ -80,4 +110,11 @@ def test_oracle_loop_matches_the_reference_pipeline_run_here(gold, case):
     assert np.abs(s2[-1][1] - s1[-1][1]).max() > 0.1 and np.array_equal(s2[:, 0], s1[:, 0])
     # one set_adapters per concept at prompt encoding (:340-342) + one per concept WITH a mask per fused step (:588-591), both stages
     n_masked = sum(m is not None for m in c["masks"])
-    assert int(gold[f"{c['name']}/set_adapters_calls"]) == 2 * c["K"] + n_masked * (c["steps"] - 16)
+    fused = c["steps"] - 16
+    if c["flow"].startswith("iid"):      # the InstantID loop never selects adapters; IdentityNet once per masked concept per fused step (stage 2 only)
+        assert int(gold[f"{c['name']}/set_adapters_calls"]) == 0
+        assert int(gold[f"{c['name']}/controlnet_calls"]) == n_masked * fused
+        assert int(gold[f"{c['name']}/controlnet2_calls"]) == (2 * c["steps"] if c["flow"] == "iid_t2i" else 0)
+    else:
+        assert int(gold[f"{c['name']}/set_adapters_calls"]) == 2 * c["K"] + n_masked * fused
+        assert int(gold[f"{c['name']}/controlnet_calls"]) == (2 * c["steps"] if c["flow"] == "lora_cn" else 0)

@@ -1,6 +1,7 @@
 """Memory-side traffic of the benchmark's largest GEMM launch, from rocprofv3 PMC counters (GPU box only).
 
-    python tools/pmc_traffic.py fp16 [out.json]        (gemm_kernel_v11 — the 256x256 tile with the ring K loop —, the shape bench.py's roofline names)
+    python tools/pmc_traffic.py fp16 [out.json] [variant word]     (gemm_kernel_v12 — the 256x256 tile with the ring K loop, persistent walk —, the shape
+                                                                    bench.py's roofline names; variant word 25 | 64 << 8 = walk groups of 4 row tiles, 25 | 128 << 8 = 2)
     python tools/pmc_traffic.py fp8  [out.json]        (gemm_mx8_kernel, same shape, GEGLU epilogue)
 
 Runs `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and, in a SEPARATE pass, `--pmc WRITE_SIZE` (the two do not fit one pass:
@@ -8,7 +9,7 @@ MI355X_MICROARCH.md, PMC slots) around tools/gemm_one.py / tools/mx8_one.py, kee
 the per-launch bytes with the guide's gfx950 correction (FETCH_SIZE counts 64 B per 128-B request: doubled).  The launch is
 the GEGLU projection of the 1280-wide transformer blocks at 8 requests per step: M 65536, N 10240, K 1280, GEGLU epilogue
 (output 65536 x 5120), i.e. what `bench.py` runs, not a plain-epilogue stand-in.
-bench.py reads profiles/r04_pmc_traffic_{fp16,fp8}.json (falling back to r03) for `roofline.traffic`.
+bench.py reads profiles/r05_pmc_traffic_{fp16,fp8}.json (falling back to r04, r03) for `roofline.traffic`.
 """
 import csv
 import glob
@@ -38,10 +39,11 @@ def one_pass(counter, cmd, match):
 
 def main():
     mode = sys.argv[1]
-    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", f"r04_pmc_traffic_{mode}.json")
+    out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", f"r05_pmc_traffic_{mode}.json")
+    word = sys.argv[3] if len(sys.argv) > 3 else "0"
     it = 4
     if mode == "fp16":
-        cmd, match = [sys.executable, "tools/gemm_one.py", str(M), str(N), str(K), "0", str(it), "geglu"], "gemm_kernel_v11"
+        cmd, match = [sys.executable, "tools/gemm_one.py", str(M), str(N), str(K), word, str(it), "geglu"], "gemm_kernel_v12"
         a_bytes, w_bytes = M * K * 2, N * K * 2
     else:
         cmd, match = [sys.executable, "tools/mx8_one.py", str(M), str(N), str(K), str(it), "geglu"], "gemm_mx8_kernel"
