@@ -173,6 +173,9 @@ def lib() -> C.CDLL:
     v = os.environ.get("OMG_GEMM_VARIANT")      # debugging/benchmarking aid: force one GEMM tile configuration
     if v:
         l.omg_debug_set_gemm_variant(int(v))
+    v = os.environ.get("OMG_ATTN_VARIANT")      # ditto for the attention kernels (bit 16: attn_fwd_kernel7 without its XCD-aware block order)
+    if v:
+        l.omg_debug_set_attn_variant(int(v, 0))
     _lib = l
     return l
 

@@ -185,6 +185,8 @@ class Attention(nn.Module):
         skey = (tuple(ctx.shape), None if st is None else (st.group_adapter.data_ptr(), st.merged))
         stamp = (ctx.data_ptr(), ctx._version)
         hit = self._kv_cache.get(skey)
+        if hit is not None:
+            self._kv_cache[skey] = self._kv_cache.pop(skey)      # most recently USED last: eviction takes the idle shape, not the oldest-inserted one
         if hit is not None and hit[0] == stamp:
             return hit[1], hit[2]
         B, Nk, Cx = ctx.shape
@@ -227,6 +229,8 @@ def _ip_kv(attn: Attention, ip_ctx: torch.Tensor):
     if cache is None:
         cache = attn._ip_cache = {}
     c = cache.get(shape)
+    if c is not None:
+        cache[shape] = cache.pop(shape)               # LRU order (see project_cross)
     if c is None or c[0] != stamp:
         Bc, Ni, Cx = shape
         kv_out = c[3] if c is not None else None

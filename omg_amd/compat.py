@@ -435,6 +435,9 @@ def _save_image(tensor, fp, nrow: int = 8, **kw) -> None:
     Image.fromarray(a[:, :, 0] if a.shape[2] == 1 else a).save(fp)
 
 
+_SAVED_DIFFUSERS: dict = {}      # a real `diffusers` set aside by install(), put back by uninstall()
+
+
 def install(stub_missing: bool = True) -> List[str]:
     """Make the reference's scripts run on this backend with their ORIGINAL import block (B3): registers, in ``sys.modules``, the module
     names ``inference_lora.py:29-32`` and ``inference_instantid.py:8-13, :34-37`` import, backed by this package —
@@ -470,7 +473,10 @@ def install(stub_missing: bool = True) -> List[str]:
         except (ImportError, ValueError):
             pass
         m = types.ModuleType(name)
-        m.__path__ = []                                         # a package: submodules are looked up in sys.modules first
+        # a package: submodules are looked up in sys.modules first (the aliases), then in the directories of that name found on sys.path NOW —
+        # a checkout's own `src/efficientvit`, `src/...` stay importable beside the aliased `src.pipelines.*` (an empty __path__
+        # shadowed them whenever the stand-in was created before the script's directory was on sys.path)
+        m.__path__ = [d for d in (os.path.join(p or os.getcwd(), *name.split(".")) for p in sys.path) if os.path.isdir(d)]
         m.__omg_amd_alias__ = True
         sys.modules[name] = m
         done.append(name)
@@ -503,11 +509,18 @@ def install(stub_missing: bool = True) -> List[str]:
     module("src.pipelines.instantid_single_pieline", InstantidSingleConceptPipeline=InstantidSingleConceptPipeline,
            StableDiffusionXLInstantIDPipeline=StableDiffusionXLInstantIDPipeline)
     module("src.prompt_attention.p2p_attention", AttentionReplace=AttentionReplace)
-    for n in ("diffusers", "diffusers.models", "diffusers.utils"):
-        sys.modules.pop(n, None)
+    # a REAL diffusers (none in this image; a user's environment may have one) is set aside whole and restored by uninstall(): the aliases never
+    # patch it (package("diffusers") imported the real package and overwrote four of its attributes for good)
+    global _SAVED_DIFFUSERS
+    _SAVED_DIFFUSERS = {n: sys.modules.pop(n) for n in [n for n in sys.modules if n == "diffusers" or n.startswith("diffusers.")]
+                        if not getattr(sys.modules[n], "__dict__", {}).get("__omg_amd_alias__", False)}
+    d = types.ModuleType("diffusers")
+    d.__path__ = []
+    d.__omg_amd_alias__ = True
+    sys.modules["diffusers"] = d
+    done.append("diffusers")
     dm = module("diffusers.models", ControlNetModel=ControlNetModel, T2IAdapter=_Unavailable("diffusers.models.T2IAdapter"))
     du = module("diffusers.utils", load_image=load_image)
-    d = package("diffusers")
     d.__dict__.update(ControlNetModel=ControlNetModel, StableDiffusionXLPipeline=StableDiffusionXLPipeline,
                       DPMSolverMultistepScheduler=_Unavailable("diffusers.DPMSolverMultistepScheduler"),
                       DDIMScheduler=DDIMScheduler, EulerDiscreteScheduler=EulerDiscreteScheduler, models=dm, utils=du)
@@ -535,3 +548,6 @@ def uninstall() -> None:
     # vars(), not getattr: lazy modules (transformers) import on attribute access and would grow sys.modules under the iteration
     for n in [n for n, m in list(sys.modules.items()) if m is not None and getattr(m, "__dict__", {}).get("__omg_amd_alias__", False)]:
         del sys.modules[n]
+    global _SAVED_DIFFUSERS
+    sys.modules.update(_SAVED_DIFFUSERS)
+    _SAVED_DIFFUSERS = {}

@@ -24,7 +24,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from .attention import Attention
-from .modules import Conv2d, bump_pointer_epoch
+from .modules import Conv2d, bump_pointer_epoch, bump_weights_version
 from .unet import (CrossAttnDownBlock2D, DownBlock2D, TimestepEmbedding, UNetConfig, UNetMidBlock2DCrossAttn, _Ctx)
 
 COND_CHANNELS = (16, 32, 96, 256)
@@ -128,6 +128,7 @@ class ControlNetModel(nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.invalidate_packed()
+        bump_weights_version(self)
         return r
 
     # the time/text embedding is the UNet's; reuse its implementation
@@ -148,6 +149,8 @@ class ControlNetModel(nn.Module):
         if cache is None:
             cache = self._cond_cache = {}
         c = cache.get(shape)
+        if c is not None:
+            cache[shape] = cache.pop(shape)               # most recently used last: the eviction below takes the idle shape
         if c is None or c[0] != stamp:
             feat = self.controlnet_cond_embedding(controlnet_cond)
             if c is not None:

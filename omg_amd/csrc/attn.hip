@@ -760,7 +760,12 @@ int g_attn_variant = 0;      // 0 = heuristic (above 128 keys: v7 when V is give
 
 static int g_attn_qchunk = 512;     // v6: query rows per workgroup strip (tools: bits 8.. of the variant word, in units of 128)
 
-extern "C" void omg_debug_set_attn_variant(int v) { g_attn_variant = v & 0xff; g_attn_qchunk = (v >> 8) ? (v >> 8) * 128 : 512; }
+static int g_attn_natural_order = 0; // v7, tools: bit 16 of the variant word = blocks in launch order instead of the XCD-aware order
+extern "C" void omg_debug_set_attn_variant(int v) {
+  g_attn_variant = v & 0xff;
+  g_attn_qchunk = ((v >> 8) & 0xff) ? ((v >> 8) & 0xff) * 128 : 512;
+  g_attn_natural_order = (v >> 16) & 1;
+}
 extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   OMG_REQUIRE(a != nullptr, "omg_attn_fwd: null args");
   OMG_REQUIRE(a->dtype == OMG_F16 || a->dtype == OMG_BF16, "omg_attn_fwd: dtype");
@@ -777,8 +782,9 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
     OMG_REQUIRE(a->ldv % 8 == 0 && a->v_bstride % 8 == 0, "omg_attn_fwd: V strides must be multiples of 8 elements");
     OMG_REQUIRE(a->Nkv > 128, "omg_attn_fwd: row-major V needs more than 128 keys (pass Vt from omg_transpose_v below that)");
     dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);
-    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel7<f16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride);
-    else OMG_LAUNCH(attn_fwd_kernel7<bf16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride);
+    const int xcd_order = g_attn_natural_order ? 0 : 1;
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel7<f16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order);
+    else OMG_LAUNCH(attn_fwd_kernel7<bf16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order);
     return omg_check_launch("attn_fwd_v7");
   }
   OMG_REQUIRE(a->Vt != nullptr, "omg_attn_fwd: this variant needs Vt");

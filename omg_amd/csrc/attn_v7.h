@@ -49,7 +49,7 @@ template <> struct MfmaInit<bf16> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int xcd_order) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
   using V8 = typename Vec<T>::v8;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
   int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   {
     const int total = gridDim.x * gridDim.y * gridDim.z;
-    if ((total & 7) == 0) {
+    if (xcd_order && (total & 7) == 0) {
       const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
       const int wi = (lin & 7) * (total >> 3) + (lin >> 3);
       qblk = wi % (int)gridDim.x;

@@ -61,26 +61,7 @@ template <> OMG_DEV void store8<float>(char* p, const float (&f)[8]) {
 OMG_DEV float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) — the IEEE division of silu_f is ten VALU instructions (GEMM epilogues)
 OMG_DEV float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// exact (erf) GELU — diffusers GEGLU uses F.gelu(gate) with the default approximate='none'.
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the half-precision rounding of the result), branch-free:
-// ~14 VALU instructions instead of libm's two-branch erff, which made the GEGLU epilogue as long as five K-steps of MFMA.
-OMG_DEV float erf_as(float x) {
-  const float ax = __builtin_fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-  float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  poly = __builtin_fmaf(poly, t, 1.421413741f);
-  poly = __builtin_fmaf(poly, t, -0.284496736f);
-  poly = __builtin_fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-  const float r = __builtin_fmaf(-poly, e, 1.0f);
-  return __builtin_copysignf(r, x);
-}
-#ifdef OMG_EXP_GELU2
-#include "gelu_v2.h"       // tools/exp/ (make GELU2=1 adds the include path): round 5's experiment — gelu_f through ONE transcendental, NOT RUN yet
-#else
-OMG_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
-#endif
+#include "gelu.h"         // gelu_f / gelu_f2: the exact (erf) GELU of the GEGLU epilogues through one transcendental
 
 // ---- MX-fp8 quantisation helpers (gemm_mx8.hip, norm.hip): E8M0 scale of a 32-block and the e4m3 element cast.
 // Scale = the smallest power of two 2^e with amax / 2^e <= 448 (the e4m3 maximum): no element saturates.  Returns e + 127.

@@ -1,20 +1,19 @@
-// tools/exp/gelu_v2.h — EXPERIMENT for round 5 (`make -C omg_amd/csrc GELU2=1` replaces common.h's gelu_f with this one; never in the product build).
-// WRITTEN IN ROUND 4 WITH NO GPU TIME LEFT: arithmetic validated on the host (tests/test_gelu_v2.py: fp32 emulation against scipy's erf), NOT RUN.
-//
-// Why: the GEGLU epilogue is VALU work with nothing to hide behind — one wave per SIMD, the MFMAs are done — and it is the largest epilogue of the
-// step: 128 gate values per lane, each through erf_as (Abramowitz & Stegun 7.1.26: v_rcp_f32 + five FMAs + v_exp_f32 + seven more instructions;
-// the emitted epilogue of the product's GEGLU kernel holds 128 v_rcp, 128 v_exp and ~1650 other VALU instructions: ~10.7 k cycles = 5.6 us of a
-// 34 us tile at K = 1280, 40 rounds per launch, 3500 launches per benchmark step = 3.4 % of the step).  Transcendentals are quarter rate.
-// This form needs ONE:   erfc(t) = 2^q(t),  q = t (c1 + c2 t + ... + c7 t^6)  (weighted minimax fit of log2 erfc on [0, 4.25], |error| of erfc
-// <= 7.8e-8 — A&S 7.1.26: 1.5e-7 — no constant term: q(0) = 0 exactly), and with h = 2^(q - 1) = erfc / 2
+// gelu.h — the exact (erf) GELU of the GEGLU epilogues (diffusers GEGLU: F.gelu(gate), approximate='none') through ONE transcendental.
+// Written in round 4, first run and landed in round 5 (profiles/r05_third_gelu2_*.log: every tile variant bitwise equal, the gate function within
+// one fp16 ulp of the float64 erf form, the GEGLU launches of the benchmark +2.3 ... 5.1 %).  It replaced erf by Abramowitz & Stegun 7.1.26
+// (v_rcp_f32 + five FMAs + v_exp_f32 + seven more instructions per gate value: the emitted GEGLU epilogue held 128 v_rcp, 128 v_exp and ~1650 other
+// VALU instructions per lane — the largest epilogue of the step, VALU work with nothing to hide behind).  Transcendentals are quarter rate.
+// This form:   erfc(t) = 2^q(t),  q = t (c1 + c2 t + ... + c7 t^6)  (weighted minimax fit of log2 erfc on [0, 4.25], |error| of erfc <= 7.8e-8 —
+// A&S 7.1.26: 1.5e-7 — no constant term: q(0) = 0 exactly), and with h = 2^(q - 1) = erfc / 2
 //     gelu(x) = x Phi(x) = max(x, 0) - |x| h          (x >= 0: x - x erfc/2;  x < 0: x erfc(|t|)/2 = -|x| h)
 // the sign handling, the 1 + erf and the 0.5 x are gone as well.  The coefficients below are in a = |x| (the 1/sqrt 2 of t folded in), a is
 // clamped to 4.25 sqrt 2 where erfc = 3e-9: clamp, eight FMAs, exp2, max, FMA.
-// Measured on the host in emulated fp32 over [-12, 12] + N(0, 2): max |gelu - exact| 3.9e-7 (erf_as form: 4.7e-7); 5.7 % of the fp16-rounded
-// outputs differ from the erf_as form's by one ulp, each as close to the correctly rounded value as the other.
+// Measured on the host in emulated fp32 over [-12, 12] + N(0, 2) (tests/test_gelu.py): max |gelu - exact| 3.9e-7 (the erf_as form: 4.7e-7); 5.7 % of
+// the fp16-rounded outputs differ from the erf_as form's by one ulp, each as close to the correctly rounded value as the other.
 // The polynomial is written on PAIRS so that its eight FMAs are four v_pk_fma_f32 (left to the SLP vectoriser the scalar form stayed scalar:
 // 872 v_fmaak / v_fma per lane instead of ~512 packed); per element the emitted code is then one v_med3 (|x| as a source modifier), four packed
-// FMAs, v_exp_f32, v_max, half a packed FMA.  The packed and the scalar FMA round identically: gelu_f (the small-tile kernels) and gelu_f2 agree bit for bit.
+// FMAs, v_exp_f32, v_max, half a packed FMA.  The packed and the scalar FMA round identically: gelu_f (the small-tile kernels) and gelu_f2 agree bit for bit
+// (tests/test_kernels_gpu.py::test_gemm_variants_are_bitwise_identical).
 typedef float omg_f32x2 __attribute__((ext_vector_type(2)));
 OMG_DEV omg_f32x2 gelu_f2(omg_f32x2 x) {
   const omg_f32x2 a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x[0]), 0.0f, 6.0104076400856545f),

@@ -332,17 +332,12 @@ OMG_DEV void epilogue_geglu(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         float o[8];
-#ifdef OMG_EXP_GELU2       // make GELU2=1 (tools/exp/gelu_v2.h): the gate's polynomial on pairs, four v_pk_fma_f32 per two elements
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
+        for (int e = 0; e < 8; e += 2) {       // the gate's polynomial on pairs: four v_pk_fma_f32 per two elements (gelu.h)
           const omg_f32x2 gl = gelu_f2(omg_f32x2{acc[i][2 * b + 1][pr * 8 + e], acc[i][2 * b + 1][pr * 8 + e + 1]});
           o[e] = acc[i][2 * b][pr * 8 + e] * gl[0] * osc;
           o[e + 1] = acc[i][2 * b][pr * 8 + e + 1] * gl[1] * osc;
         }
-#else
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = acc[i][2 * b][pr * 8 + e] * gelu_f(acc[i][2 * b + 1][pr * 8 + e]) * osc;
-#endif
         if constexpr (XE) xe_put<T, 128>(cx, 4 * b + 2 * pr, o);
         else store_runs<T>(cx.rsC, ro | cx.voob[2 * b][pr], (b * 32 + pr * 16) * 2, o);
         __builtin_amdgcn_sched_barrier(0);

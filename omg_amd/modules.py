@@ -42,6 +42,13 @@ def pointer_epoch() -> int:
     return _POINTER_EPOCH[0]
 
 
+def bump_weights_version(net) -> None:
+    """``net.weights_version``: advances whenever the numbers a forward of ``net`` produces may change without its inputs changing — a state
+    dict loaded, a layer class moved between 16-bit and MX-fp8.  Part of the stage cache's key (pipeline.StageCache; ADVICE r4: `id(unet)` alone
+    let a precision change or a weight reload between the stage-1 and the stage-2 call resume from the other weights' latents)."""
+    net.weights_version = getattr(net, "weights_version", 0) + 1
+
+
 def bump_pointer_epoch() -> None:
     _POINTER_EPOCH[0] += 1
 

@@ -172,6 +172,39 @@ class StageCache:
         return b
 
 
+# Parameters of the reference's ``__call__`` (lora_pipeline.py:212-255, instantid_pipeline.py:215-259) that change ITS output when they leave their
+# default and that this engine does not implement: name -> (the default, where the reference uses it).  A non-default value is REFUSED — ignoring
+# it would return an image the reference would not have produced, without a word.
+_UNIMPLEMENTED = {
+    "guess_mode": (False, "lora_pipeline.py:236, :497-503 (ControlNet on the conditional rows only)"),
+    "control_guidance_start": (0.0, "lora_pipeline.py:237, :421-428 (controlnet_keep)"),
+    "control_guidance_end": (1.0, "lora_pipeline.py:238, :421-428 (controlnet_keep)"),
+    "callback": (None, "lora_pipeline.py:256, :629-632"), "callback_steps": (None, "lora_pipeline.py:257"),
+    "callback_on_step_end": (None, "lora_pipeline.py:246, :617-626"),
+    "prompt_2": (None, "lora_pipeline.py:215 (second text encoder's own prompt)"), "negative_prompt_2": (None, "lora_pipeline.py:222"),
+    "num_images_per_prompt": (1, "lora_pipeline.py:223"), "ip_adapter_image": (None, "lora_pipeline.py:231"),
+    "clip_skip": (None, "lora_pipeline.py:245"), "negative_original_size": (None, "lora_pipeline.py:242, :459-466"),
+    "negative_target_size": (None, "lora_pipeline.py:244, :459-466"), "negative_crops_coords_top_left": ((0, 0), "lora_pipeline.py:243"),
+}
+# names the reference's own ``**kwargs`` swallows without reading (the shipped scripts pass them: inference_lora.py:241-245), or reads only
+# together with a callback
+_REFERENCE_IGNORES = ("spatial_condition", "indices_to_alter", "callback_on_step_end_tensor_inputs")
+
+
+def refuse_unimplemented(given: dict, leftovers: dict, who: str) -> None:
+    """``given``: the reference-signature parameters this engine does not implement, as the caller passed them; ``leftovers``: what is
+    still in ``**kwargs`` after the engine took its own.  Raises OmgHipError for a non-default reference parameter and for a name nobody knows."""
+    for name, value in given.items():
+        default, where = _UNIMPLEMENTED[name]
+        v = value[0] if isinstance(value, (list, tuple)) and len(value) == 1 and not isinstance(default, tuple) else value
+        v = tuple(v) if isinstance(default, tuple) and isinstance(v, (list, tuple)) else v
+        if not (v is default or v == default):
+            raise L.OmgHipError(f"{who}: {name}={value!r} is not implemented (the reference uses it at {where}); only the default {default!r} is")
+    unknown = [k for k in leftovers if k not in _REFERENCE_IGNORES]
+    if unknown:
+        raise L.OmgHipError(f"{who}: unknown keyword argument(s) {sorted(unknown)} — neither a parameter of the reference's __call__ nor one of this engine's")
+
+
 class StableDiffusionXLPipelineOutput(SimpleNamespace):
     pass
 
@@ -236,6 +269,15 @@ class LoraMultiConceptPipeline:
                  use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START,
                  lora_mode: str = "merged", dedup: bool = False, **kwargs):
         controlnet = kwargs.pop("controlnet", getattr(self, "controlnet", None))
+        cn_scale = kwargs.pop("controlnet_conditioning_scale", 1.0)
+        stage_cache, drop_unc0 = kwargs.pop("stage_cache", None), kwargs.pop("drop_unc0", False)
+        given = {k: kwargs.pop(k) for k in list(kwargs) if k in _UNIMPLEMENTED}
+        given.update(prompt_2=prompt_2, negative_prompt_2=negative_prompt_2, num_images_per_prompt=num_images_per_prompt)
+        refuse_unimplemented(given, kwargs, "LoraMultiConceptPipeline.__call__")
+        if isinstance(cn_scale, (list, tuple)):          # lora_pipeline.py:513-515: one ControlNet takes the first entry
+            cn_scale = cn_scale[0]
+        if isinstance(image, (list, tuple)) and image is not None and len(image) != 1:
+            raise L.OmgHipError("a list of ControlNet images (MultiControlNetModel, lora_pipeline.py:171-172) is not implemented: pass one image")
         if image is not None and controlnet is None:
             raise L.OmgHipError("image= needs a ControlNet: pass controlnet=omg_amd.controlnet.ControlNetModel(...)")
         if eta != 0.0:
@@ -276,8 +318,7 @@ class LoraMultiConceptPipeline:
                                  controller=controller, concept_models=concept_models, stage=stage, lora_list=lora_list,
                                  styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
                                  lora_mode=lora_mode, controlnet=controlnet if image is not None else None, controlnet_image=image,
-                                 controlnet_conditioning_scale=kwargs.pop("controlnet_conditioning_scale", 1.0), dedup=dedup,
-                                 stage_cache=kwargs.pop("stage_cache", None), drop_unc0=kwargs.pop("drop_unc0", False))[0]
+                                 controlnet_conditioning_scale=cn_scale, dedup=dedup, stage_cache=stage_cache, drop_unc0=drop_unc0)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         images = self._postprocess(lat, output_type)
@@ -489,13 +530,17 @@ class LoraMultiConceptPipeline:
         cache_keys: List[str] = []
         cache_hit = None
         base_traj = None                      # drop_unc0: per step k the (n, C, H, W) latents / model inputs of the base samples
+        if use_cn and controlnet_image.shape[0] not in (1, n):
+            # one conditioning image per MAIN ROW (4n): the cache key and drop_unc0's compact rows address images per REQUEST — not built for
+            # that layout (the full batch below handles it); neither is used instead of being keyed / indexed wrongly
+            stage_cache, drop_unc0 = None, False
         if stage_cache is not None and shard is None and S > fusion_start + 1:
             common = (S, float(guidance_scale), type(self.scheduler).__name__, fusion_start, height, width, tuple(original_size),
                       tuple(crops_coords_top_left), tuple(target_size), str(dt), tuple(main_adapters), main_scale, lora_mode if main_adapters else None,
-                      id(self.unet), getattr(bank, "version", None) if main_adapters else None,
+                      id(self.unet), getattr(self.unet, "weights_version", 0), getattr(bank, "version", None) if main_adapters else None,
                       None if controller is None else (type(controller).__name__, getattr(controller, "is_pure_replacement", False),
                                                        getattr(controller, "num_self_replace", None)),
-                      None if not use_cn else (id(controlnet), float(controlnet_conditioning_scale)))
+                      None if not use_cn else (id(controlnet), getattr(controlnet, "weights_version", 0), float(controlnet_conditioning_scale)))
             coef_key = self.scheduler.coef_table(dev)
             for j in range(n):
                 cn_img = None if not use_cn else (controlnet_image if controlnet_image.shape[0] == 1 else controlnet_image[j: j + 1])
@@ -898,6 +943,10 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
         ``cross_attention_kwargs=None`` (:665-674): LoRA scale 1.0."""
         if prompt_embeds is None:
             raise L.OmgHipError("pass prompt_embeds=/pooled_prompt_embeds= (text encoders are outside this package's scope)")
+        stage_cache = kwargs.pop("stage_cache", None)
+        for dead in ("face_app", "prompt", "negative_prompt"):      # consumed by omg_amd.compat's front end when the scripts call it; dead here
+            kwargs.pop(dead, None)
+        refuse_unimplemented({k: kwargs.pop(k) for k in list(kwargs) if k in _UNIMPLEMENTED}, kwargs, "InstantidMultiConceptPipeline.__call__")
         K = len(region_prompt_embeds or [])
         # stage 1 is called with image=None: no IdentityNet (instantid_pipeline.py:393, :426-428)
         use_idn = stage == 2 and image is not None
@@ -915,7 +964,7 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                                  controlnet_conditioning_scale=t2i_controlnet_conditioning_scale, dedup=dedup, concept_lora=False,
                                  cross_attention_kwargs=cross_attention_kwargs, main_adapters=main_adapters,
                                  concept_adapters=concept_adapters, concept_adapter_scale=1.0, lora_mode=lora_mode,
-                                 stage_cache=kwargs.pop("stage_cache", None))[0]
+                                 stage_cache=stage_cache)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         lat = self._postprocess(lat, output_type)

@@ -3,10 +3,12 @@
     python -m omg_amd.run /path/to/OMG/inference_lora.py --prompt "..." --lora_path "..." ...
     python -m omg_amd.run /path/to/OMG/inference_instantid.py ...
 
-What it does, in this order: ``omg_amd.compat.install()`` (alias modules for ``src.pipelines.*``, ``src.prompt_attention.p2p_attention`` and
-``diffusers``: INTEGRATION.md §1), the script's own directory in front of ``sys.path`` (as ``python script.py`` would put it, so that the
-checkout's other ``src.*`` packages — detectors, segmenters — resolve to the reference's own files), ``sys.argv`` = the script and its
-arguments, then ``runpy.run_path(script, run_name="__main__")``.  Nothing of the script is edited or copied."""
+What it does, in this order: the script's own directory in front of ``sys.path`` (as ``python script.py`` would put it, so that the
+checkout's other ``src.*`` packages — detectors, segmenters — resolve to the reference's own files WHATEVER the current directory is: the
+alias package ``src`` that ``install()`` registers lists the ``src`` directories found on ``sys.path`` at that moment as its ``__path__``),
+``omg_amd.compat.install()`` (alias modules for ``src.pipelines.*``, ``src.prompt_attention.p2p_attention`` and ``diffusers``:
+INTEGRATION.md §1), ``sys.argv`` = the script and its arguments, then ``runpy.run_path(script, run_name="__main__")``.  Nothing of the
+script is edited or copied."""
 import os
 import runpy
 import sys
@@ -21,8 +23,8 @@ def main(argv=None) -> None:
     if not os.path.isfile(script):
         raise SystemExit(f"omg_amd.run: no such script: {argv[0]}")
     from . import compat
+    sys.path.insert(0, os.path.dirname(script))          # BEFORE install(): its stand-in for `src` must see the checkout's own src/ directory
     registered = compat.install()
-    sys.path.insert(0, os.path.dirname(script))
     sys.argv = [script] + argv[1:]
     try:
         runpy.run_path(script, run_name="__main__")

@@ -32,7 +32,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from .attention import Attention, FusedAttnProcessor
-from .modules import Conv2d, GEGLU, GroupNorm, LayerNorm, Linear, LoraState, bump_pointer_epoch
+from .modules import Conv2d, GEGLU, GroupNorm, LayerNorm, Linear, LoraState, bump_pointer_epoch, bump_weights_version
 
 
 @dataclass
@@ -305,6 +305,7 @@ def set_mx8_classes(net, classes, select=None) -> int:
         n_on += int(new)
     if changed:      # step graphs captured under the other precision launch the other kernels: drop them (pipeline.run_step)
         bump_pointer_epoch()
+        bump_weights_version(net)
     return n_on
 
 
@@ -389,6 +390,7 @@ class UNet2DConditionModel(nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.invalidate_packed()
+        bump_weights_version(self)
         return r
 
     def init_synthetic_(self, seed: int = 0, qk_gain: float = 1.0) -> "UNet2DConditionModel":
@@ -431,6 +433,7 @@ class UNet2DConditionModel(nn.Module):
         self.linear_precision = mode
         if changed:      # step graphs captured under the other precision launch the other kernels: drop them (pipeline.run_step)
             bump_pointer_epoch()
+            bump_weights_version(self)
 
     def set_conv_precision(self, mode: str = "fp16") -> None:
         """``"mx8"``: conv1 / conv2 of every ResnetBlock2D run as MX-fp8 implicit GEMMs (omg_conv2d_mx8) on the feature map their
@@ -447,9 +450,12 @@ class UNet2DConditionModel(nn.Module):
         self.conv_precision = mode
         if changed:
             bump_pointer_epoch()
+            bump_weights_version(self)
 
     def set_precision_classes(self, classes, select=None) -> int:
         """Per-class MX-fp8 map (:func:`set_mx8_classes`); ``set_linear_precision("mx8")`` + ``set_conv_precision("mx8")`` = every class."""
+        if isinstance(classes, str):          # a preset name or one class name, as set_mx8_classes resolves it (ADVICE r4: set("none") = {'n','o','e'})
+            classes = MX8_PRESETS.get(classes, (classes,))
         n = set_mx8_classes(self, classes, select)
         cl = set(classes or ())
         self.linear_precision = "mx8" if cl - {"conv1", "conv2"} else "fp16"

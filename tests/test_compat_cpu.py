@@ -153,3 +153,41 @@ def test_mx8_layer_class_map_on_the_module_tree(dirs):
     n_cn = cn.set_precision_classes(MX8_CLASSES)
     assert n_cn == sum(1 for _, m in cn.named_modules() if isinstance(m, (Linear, Conv2d)) and getattr(m, "mx8", False))
     assert cn.set_precision_classes(()) == 0
+
+
+def test_run_module_resolves_the_checkouts_own_src_packages_from_a_foreign_cwd(tmp_path, monkeypatch):
+    """`python -m omg_amd.run /path/OMG/script.py` started OUTSIDE the checkout.  The alias package `src` must not shadow the checkout's
+    real `src.*` packages (detectors, segmenters): a driver whose sibling `src/efficientvit_stub/...` is importable from its own directory must
+    be importable here too, while `src.pipelines.lora_pipeline` resolves to the alias.  A real `diffusers` in sys.modules survives the round trip."""
+    import sys
+    import types
+    from omg_amd import compat, run
+    co = tmp_path / "OMG"
+    (co / "src" / "segmenter_stub").mkdir(parents=True)
+    (co / "src" / "segmenter_stub" / "__init__.py").write_text("ANSWER = 42\n")
+    (co / "driver.py").write_text(
+        "import json, sys\n"
+        "from src.segmenter_stub import ANSWER\n"
+        "from src.pipelines.lora_pipeline import LoraMultiConceptPipeline\n"
+        "import diffusers\n"
+        "json.dump({'answer': ANSWER, 'pipe': LoraMultiConceptPipeline.__module__, 'alias': getattr(diffusers, '__omg_amd_alias__', False)}, open(sys.argv[1], 'w'))\n")
+    out = tmp_path / "out.json"
+    elsewhere = tmp_path / "elsewhere"
+    elsewhere.mkdir()
+    monkeypatch.chdir(elsewhere)
+    real = types.ModuleType("diffusers"); real.MARK = "real"
+    real_sub = types.ModuleType("diffusers.models"); real_sub.MARK = "real.models"
+    monkeypatch.setitem(sys.modules, "diffusers", real)
+    monkeypatch.setitem(sys.modules, "diffusers.models", real_sub)
+    for n in [n for n in sys.modules if n == "src" or n.startswith("src.")]:
+        monkeypatch.delitem(sys.modules, n)
+    path0 = list(sys.path)
+    try:
+        run.main([str(co / "driver.py"), str(out)])
+    finally:
+        sys.path[:] = path0
+    import json
+    got = json.load(open(out))
+    assert got == {"answer": 42, "pipe": "omg_amd.compat", "alias": True}
+    assert sys.modules["diffusers"] is real and sys.modules["diffusers.models"] is real_sub and not hasattr(real, "ControlNetModel")
+    assert not any(getattr(m, "__dict__", {}).get("__omg_amd_alias__", False) for m in list(sys.modules.values()) if m is not None)

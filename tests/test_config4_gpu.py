@@ -179,6 +179,7 @@ def _fresh(octl, args):
     return o
 
 
+@pytest.mark.slow
 def test_fifty_step_error_growth_mx8(dev):
     """The 50-step curve VERDICT r2 asks for beside r02_error_growth_fp16.json: BASELINE configs[1]'s loop (50 DDIM steps, fusion for
     i > 15, 20-step self-replace window, guidance 7.5, two LoRA concepts with overlapping masks) with every eligible Linear and

@@ -1,4 +1,4 @@
-"""tools/exp/gelu_v2.h (round 5's GELU experiment: `make -C omg_amd/csrc GELU2=1`) on the host: the constants are read out of the header and its
+"""omg_amd/csrc/gelu.h (the GEGLU gate function, landed in round 5) on the host: the constants are read out of the header and its
 arithmetic — clamp, eight fp32 FMAs, exp2, max, FMA — is emulated in fp32 (every FMA rounded once) against scipy's erf.  What is asserted is what
 the header claims: no less accurate than the erf_as form (Abramowitz & Stegun 7.1.26) it replaces, q(0) = 0, saturation for large |x|."""
 import os
@@ -9,7 +9,7 @@ import pytest
 
 scipy_special = pytest.importorskip("scipy.special")
 
-HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp", "gelu_v2.h")
+HDR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "omg_amd", "csrc", "gelu.h")
 f32 = np.float32
 
 

@@ -218,3 +218,24 @@ def test_controller_source_vector_without_the_base_unconditional_row():
     assert ctl.fused_qk_src(True, 16, 3, device="cpu", total_batch=3, images=1).tolist() == [0, 1, 1]
     with pytest.raises(ValueError):
         ctl.fused_qk_src(True, 16, 5, device="cpu")
+
+
+def test_reference_parameters_that_are_not_implemented_are_refused_not_ignored():
+    """B3: a non-default value of a parameter the reference's __call__ acts on (guess_mode, control_guidance_start / _end -> controlnet_keep,
+    callbacks, prompt_2, ...) must raise — silently dropping it returns an image the reference would not have produced; names nobody knows raise
+    too; what the shipped scripts pass and the reference itself never reads (inference_lora.py:241-245 `spatial_condition`) is accepted."""
+    from omg_amd import _lib as L
+    from omg_amd.pipeline import InstantidMultiConceptPipeline, LoraMultiConceptPipeline, refuse_unimplemented
+
+    lp, ip = object.__new__(LoraMultiConceptPipeline), object.__new__(InstantidMultiConceptPipeline)
+    for bad in (dict(guess_mode=True), dict(control_guidance_start=0.2), dict(control_guidance_end=[0.8]), dict(callback_on_step_end=print),
+                dict(callback=print, callback_steps=1), dict(prompt_2="x"), dict(num_images_per_prompt=2), dict(clip_skip=2),
+                dict(negative_original_size=(512, 512)), dict(guidance_rescale=0.7), dict(denoising_end=0.8), dict(no_such_argument=1)):
+        with pytest.raises(L.OmgHipError):
+            lp(**bad)
+        if "prompt_2" not in bad and "num_images_per_prompt" not in bad:
+            with pytest.raises(L.OmgHipError):
+                ip(prompt_embeds=torch.zeros(2, 77, 8), **bad)
+    # defaults in any of the reference's spellings, and the names its **kwargs swallows, pass the gate
+    refuse_unimplemented(dict(guess_mode=False, control_guidance_start=[0.0], control_guidance_end=1.0, callback=None, negative_crops_coords_top_left=[0, 0]),
+                         dict(spatial_condition=None, indices_to_alter=None, callback_on_step_end_tensor_inputs=["latents"]), "test")

@@ -57,6 +57,37 @@ def test_unet_plain_matches_oracle(dev, dtype):
     assert torch.equal(y, y2), "forward must be bitwise deterministic"
 
 
+@pytest.mark.parametrize("lh,lw", [(36, 28), (20, 44)])
+def test_unet_nonsquare_latents_match_oracle(dev, lh, lw):
+    """B3 / B4 with height != width: 1152 x 896 is latent 144 x 112 — here the same aspect at the tiny topology's scale (36 x 28: 252 and 63 tokens,
+    neither a multiple of the 64-row attention blocks; 20 x 44: odd halves at the deepest level are excluded by the /4 divisibility the UNet needs)."""
+    dtype = torch.float16
+    cfg, ocfg, sd, unet = build(dtype, dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, lh, lw, generator=g)
+    ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).to(dtype).float()
+    te = torch.randn(2, cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim, generator=g).to(dtype).float()
+    tid = torch.tensor([[lh * 8.0, lw * 8.0, 0, 0, lh * 8.0, lw * 8.0]] * 2)
+    y = run(unet, x, 441, ctx, te, tid, dev, dtype)
+    ref = ou.unet_forward(sd, ocfg, x, 441, ctx, te, tid)
+    assert y.shape == ref.shape == (2, 4, lh, lw)
+    err = (y - ref).abs().max().item()
+    print(f"nonsquare {lh}x{lw}: max|d|={err:.3e} ref_rms={ref.pow(2).mean().sqrt():.3f}")
+    assert err < TOL[dtype]
+    # ... and through the fused controller path with width != height (the self-replace threshold is width * height tokens)
+    args = ([P, P], 10, {"default_": 1.0}, 0.4, lw // 4, lh // 4)
+    pctl, octl = pc.AttentionReplace(*args, device=dev), oc.AttentionReplaceOracle(*args)
+    revise_regionally_controlnet_forward(unet, pctl)
+    octl.num_att_layers = pctl.num_att_layers
+    x4, ctx4, te4, tid4 = x.repeat(2, 1, 1, 1), ctx.repeat(2, 1, 1), te.repeat(2, 1), tid.repeat(2, 1)
+    x4[2:] += 0.1 * torch.randn(2, 4, lh, lw, generator=g)
+    y4 = run(unet, x4, 441, ctx4, te4, tid4, dev, dtype)
+    ref4 = ou.unet_forward(sd, ocfg, x4, 441, ctx4, te4, tid4, attn_fn=oc.reference_attn_fn(octl))
+    err4 = (y4 - ref4).abs().max().item()
+    print(f"nonsquare {lh}x{lw} with the controller: max|d|={err4:.3e}")
+    assert err4 < TOL[dtype] and (pctl.cur_step, pctl.cur_att_layer) == (1, 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16])
 def test_unet_fused_controller_matches_reference_sequence(dev, dtype):
     """Two consecutive forwards through the installed RegionControlNet_AttnProcessor: self-replace window

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${ROUND:-r05}      # ROUND=r04 reproduces the names of profiles/r04_*
 mkdir -p $O
-python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest_gpu.log 2>&1
+OMG_RUN_SLOW=1 python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest_gpu.log 2>&1
 tail -22 $O/pytest_gpu.log
 python bench.py --gpus 1 --steps ${STEPS:-3} --warmup ${WARMUP:-1} --by-shape $O/by_shape_fp16_${TAG:-v1}.txt > $O/bench_fp16_${TAG:-v1}.json 2> $O/bench_fp16_${TAG:-v1}.err
 head -c 900 $O/bench_fp16_${TAG:-v1}.json; echo
