@@ -421,6 +421,8 @@ int launch_v12_form(const GemmP& p, hipStream_t s, int mrows) {
   const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
   if (p.act == OMG_ACT_GEGLU) return launch_v12<T, CONV, 3>(p, s, mrows);
   if (gb_rows || p.act == OMG_ACT_SILU) return launch_v12<T, CONV, 4>(p, s, mrows);
-  if (p.residual != nullptr) return launch_v12<T, CONV, 2>(p, s, mrows);
+  // tools: debug bit 8 sends a residual launch to the persistent generic form (4: residual by register-direct loads, decided per unit at run
+  // time) instead of the one-tile-per-block LDS-staged form (2) — the A/B of DESIGN §8
+  if (p.residual != nullptr) return (g_dbg & 256) ? launch_v12<T, CONV, 4>(p, s, mrows) : launch_v12<T, CONV, 2>(p, s, mrows);
   return launch_v12<T, CONV, 1>(p, s, mrows);
 }

@@ -14,7 +14,9 @@ Follows, by file:line of /root/reference:
 PINNED: tests/golden/controller_golden.npz was generated in this container by importing the
 reference's own ``src/prompt_attention`` (tests/golden/make_golden.py); tests/test_oracle.py
 checks this restatement against it bit-for-bit (facts T1-T6 of SURVEY.md §4.3 and random
-probability tensors).
+probability tensors).  Round 5: ``reference_attn_fn`` + ``AttentionReplaceOracle`` inside a whole two-stage loop are compared with the
+reference's own ``RegionControlNet_AttnProcessor`` + ``AttentionReplace`` executing at all 34 attention layers of the same loop
+(tests/golden/make_golden_loop.py -> tests/test_oracle_loop.py: stage 1 bit-equal, stage 2 within one fp32 ulp).
 """
 from __future__ import annotations
 

@@ -10,7 +10,7 @@ C = heads * 64
 q = torch.randn(B, Nq, C, device=dev, dtype=torch.float16)
 k = torch.randn(B, Nkv, C, device=dev, dtype=torch.float16) * 1.5
 vv = torch.randn(B, Nkv, C, device=dev, dtype=torch.float16)
-vt = ops.transpose_v(vv, heads)
+vt = ops.value_operand(vv, heads)          # above 128 keys: the row-major view itself (attn_fwd_kernel7), else the V^T image
 out = torch.empty(B, Nq, C, device=dev, dtype=torch.float16)
 for _ in range(it):
     ops.attention(q, k, vt, heads, 0.125, out=out)

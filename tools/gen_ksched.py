@@ -1,5 +1,5 @@
-"""Generates omg_amd/csrc/gemm_v11_sched.inc: straight-line K-loop stage bodies of the experimental 256x256 four-wave GEMM
-(gemm_v11.h) from schedule tables.  A stage is 32 slots of two MFMAs; a table places the 32 fragment reads, the 16 LDS-DMA
+"""Generates omg_amd/csrc/gemm_v12_sched.inc: straight-line K-loop stage bodies of the 256x256 four-wave GEMM
+(gemm_v12.h) from schedule tables.  A stage is 32 slots of two MFMAs; a table places the 32 fragment reads, the 16 LDS-DMA
 instructions and the barrier.  The counted `s_waitcnt lgkmcnt(N)` in front of each k-step is derived here (LDS returns in order).
     python tools/gen_ksched.py            # rewrites the .inc (committed; hipcc needs no python at build time)
 Rules checked: a read of set k in a slot < 8k serves THIS stage (current buffer, before the barrier); in a slot >= 8k+8 the NEXT stage

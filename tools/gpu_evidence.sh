@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 evidence at HEAD, one GPU call:  gpurun --timeout 2400 -- 'bash tools/gpu_evidence.sh'
+# Evidence at HEAD, one GPU call:  gpurun --timeout 2400 -- 'bash tools/gpu_evidence.sh'
 # rocprofv3 kernel statistics of one eager bench step, the PMC traffic of the kernel bench.py's roofline names, the GEMM and attention PMC
 # summaries, the attention microbenchmark, the library comparison.  Everything lands under gpurun_out/${ROUND:-r05}/ (copy to profiles/ to commit).
 cd $GRAFT_REPO_ROOT

@@ -1,6 +1,6 @@
 """PMC view of the two attention kernels at the benchmark's shapes (GPU box only):  python tools/pmc_attention.py [out.json]
 
-  self   attn_fwd_kernel3, (64, 10, 4096, 4096):  SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (+ SQ wait / active counters) in one pass
+  self   attn_fwd_kernel7, (64, 10, 4096, 4096):  SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE (+ SQ wait / active counters) in one pass
   cross  attn_fwd_kernel6, (64, 20, 1024, 77):    the same pass, then FETCH_SIZE and WRITE_SIZE in two further passes (they do not share one)
 
 MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); a 32x32x16 MFMA is 32 busy cycles.  FETCH_SIZE is
@@ -32,10 +32,10 @@ def one_pass(counters, cmd, match):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_pmc_attention.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_pmc_attention.json")
     sq = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]
     rec = {"method": __doc__}
-    for name, shape, match in (("self", (64, 10, 4096, 4096), "attn_fwd_kernel3"), ("cross", (64, 20, 1024, 77), "attn_fwd_kernel6")):
+    for name, shape, match in (("self", (64, 10, 4096, 4096), "attn_fwd_kernel7"), ("cross", (64, 20, 1024, 77), "attn_fwd_kernel6")):
         B, H, Nq, Nkv = shape
         cmd = [sys.executable, "tools/attn_one.py", str(B), str(H), str(Nq), str(Nkv), "0", "4"]
         d = one_pass(sq, cmd, match)

@@ -2,7 +2,7 @@
 
 One rocprofv3 pass per shape with the SQ counters that fit together (MI355X_MICROARCH.md, PMC slots): SQ_VALU_MFMA_BUSY_CYCLES,
 GRBM_GUI_ACTIVE, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY, SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE — for the product
-kernel (variant 25 = gemm_kernel_v11, ring K loop) on the GEGLU projection 65536 x 10240 x 1280, the FF-out projection 65536 x 1280 x 5120 and
+kernel (variant 25 = gemm_kernel_v12, ring K loop, persistent walk) on the GEGLU projection 65536 x 10240 x 1280, the FF-out projection 65536 x 1280 x 5120 and
 8192^3.  MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128) (8 XCDs count GUI_ACTIVE each; 1024 SIMDs; a 32x32x16 MFMA is 32 busy
 cycles); the SQ_WAIT_* / SQ_ACTIVE_* counters are quad-cycles summed over waves, reported as shares of SQ_WAVE_CYCLES.  Counter runs clock
 lower than un-profiled ones: ratios, not times, are the result."""
@@ -28,13 +28,13 @@ def one_pass(counters, cmd, match):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_pmc_gemm.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_pmc_gemm.json")
     rec = {"method": __doc__, "shapes": {}}
     for M, N, K, geglu in ((65536, 10240, 1280, True), (65536, 1280, 5120, False), (8192, 8192, 8192, False)):
         cmd = [sys.executable, "tools/gemm_one.py", str(M), str(N), str(K), "25", "4"] + (["geglu"] if geglu else [])
-        d, names = one_pass(SQ, cmd, "gemm_kernel_v11")
+        d, names = one_pass(SQ, cmd, "gemm_kernel_v12")
         if not d:
-            raise SystemExit("no dispatch of gemm_kernel_v11 in the counter collection")
+            raise SystemExit("no dispatch of gemm_kernel_v12 in the counter collection")
         c = d[-1]
         wc = c["SQ_WAVE_CYCLES"]
         rec["shapes"][f"{M}x{N}x{K}" + (" geglu" if geglu else "")] = {

@@ -6,7 +6,7 @@ x = hi + mid + lo (three bf16 terms = 24 significant bits) turns one exact-fp32 
 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid), i.e. an implicit GEMM with six times the K on the bf16 MFMA; a two-term split (16 bits,
 hi.hi, hi.lo, lo.hi) is three times the K.  This probe times, for every 3x3 convolution shape of the SDXL decoder's fp32 up blocks (two
 1024^2 images per call), the shipped exact kernel (omg_conv2d_f32 on v_mfma_f32_32x32x2_f32) and the shipped bf16 implicit-GEMM convolution
-(omg_conv2d, gemm_kernel_v11 / v7) on an input with 6x / 3x the channels — the arithmetic a split kernel would execute, WITHOUT the cost of
+(omg_conv2d, gemm_kernel_v12 / v13 / v7) on an input with 6x / 3x the channels — the arithmetic a split kernel would execute, WITHOUT the cost of
 writing the [hi | mid | lo] feature maps (GroupNorm + SiLU would have to) and of an fp32-output epilogue: a lower bound on its time."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
