@@ -83,9 +83,10 @@ OMG_DEV TileV12 decode_tile_v12(const GemmP& p, int vb, int ntiles) {
   const int grp = bid / tiles_per_group;
   const int t_in = bid - grp * tiles_per_group;
   // G row tiles x all column tiles form a walk group: the 32 CUs of an XCD run G x (32 / G) tiles at a time and fetch G + 32 / G operand panels
-  // for them (8 x 4: 12 panels per 32 tiles = 0.375 per tile — exactly the measured fabric reads, profiles/r04_pmc_traffic_fp16.json).  tools:
-  // debug bits 6-7 halve G (4, 2, 1) for the traffic experiment of DESIGN §8
-  const int G = 8 >> ((p.dbg >> 6) & 3);
+  // for them — 8 x 4 and 4 x 8 both 12 panels per 32 tiles = 0.375 per tile, which IS the measured fabric read volume (2.52 GB per launch of
+  // 65536 x 10240 x 1280 against 0.19 GB of operands; round 5 measured G = 4: the same 2.517 GB, the same time; G = 2: 18 panels, 1 ... 3 % slower —
+  // profiles/r05_walk_group_ab.log, r05_pmc_traffic_fp16*.json).  The traffic is the price of 32 concurrent tiles per L2, not of the walk order.
+  constexpr int G = 8;
   const int per_group = G * p.tiles_n;
   const int gid = t_in / per_group;
   const int first_m = gid * G;
@@ -421,8 +422,8 @@ int launch_v12_form(const GemmP& p, hipStream_t s, int mrows) {
   const bool gb_rows = p.group_bias != nullptr && p.rows_per_group % 256 != 0;       // == !fold_group_bias
   if (p.act == OMG_ACT_GEGLU) return launch_v12<T, CONV, 3>(p, s, mrows);
   if (gb_rows || p.act == OMG_ACT_SILU) return launch_v12<T, CONV, 4>(p, s, mrows);
-  // tools: debug bit 8 sends a residual launch to the persistent generic form (4: residual by register-direct loads, decided per unit at run
-  // time) instead of the one-tile-per-block LDS-staged form (2) — the A/B of DESIGN §8
-  if (p.residual != nullptr) return (g_dbg & 256) ? launch_v12<T, CONV, 4>(p, s, mrows) : launch_v12<T, CONV, 2>(p, s, mrows);
+  // (round 5, profiles/r05_res_form_ab_*.log: sending residual launches to the PERSISTENT generic form 4 — residual by register-direct loads —
+  // instead of this one-tile-per-block LDS-staged form was 1 ... 4 % slower on seven of nine shapes: the staged residual wins over the tile walk)
+  if (p.residual != nullptr) return launch_v12<T, CONV, 2>(p, s, mrows);
   return launch_v12<T, CONV, 1>(p, s, mrows);
 }
