@@ -141,6 +141,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
       __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)vs_, (attn_lds_ptr_t)(smem + (2 + buf) * TILE + (w + 4 * j) * 1024), 16, 0, 0);
     }
   };
+  // whole tiles: the lane's two K rows and two V rows advance by 64 keys per tile — running 64-bit pointers, one add each.  Recomputing
+  // `base + key * ld * 2` per tile (above, kept for the ragged last tile's clamp) was 8 v_mul_lo_u32 + 4 v_mad_u64_u32 per tile and wave: quarter-rate
+  // integer multiplies, ~15 % of the loop's VALU cycles in a kernel that is bound by them (round 5, found reading the emitted loop)
+  const char* kp[2];
+  const char* vp[2];
+  const long kstep = (long)KVB * p.ldk * 2, vstep = (long)KVB * ldv * 2;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    kp[j] = kbase + (long)srow[j] * p.ldk * 2 + schunk[j];
+    vp[j] = vbase + (long)srow[j] * ldv * 2 + schunk[j];
+  }
+  auto dma_whole = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)kp[j], (attn_lds_ptr_t)(smem + buf * TILE + (w + 4 * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)vp[j], (attn_lds_ptr_t)(smem + (2 + buf) * TILE + (w + 4 * j) * 1024), 16, 0, 0);
+      kp[j] += kstep;
+      vp[j] += vstep;
+    }
+  };
 
   f32x16 o[QW][2], negm[QW];
   float m_ref[QW], l_run[QW];
@@ -153,14 +173,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 
   const int ntiles = (p.Nkv + KVB - 1) / KVB;
   const int nfull = p.Nkv / KVB;             // tiles with 64 real keys
-  dma_tile(0, 0);
+  if (nfull > 0) dma_whole(0); else dma_tile(0, 0);
   auto tile_body = [&](const int t, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = t & 1;
     const int kv0 = t * KVB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile t has landed
     __syncthreads();                                     // ... everybody's has, and nobody reads buffer buf^1 any more
-    if (t + 1 < ntiles) dma_tile(kv0 + KVB, buf ^ 1);
+    if (t + 1 < nfull) dma_whole(buf ^ 1);                       // the next tile has 64 real keys
+    else if (t + 1 < ntiles) dma_tile(kv0 + KVB, buf ^ 1);       // the ragged last tile: clamped rows
     const char* kt = smem + buf * TILE;
     const char* vt = smem + (2 + buf) * TILE;
 
@@ -188,7 +209,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
       for (int r = 1; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][0][r]), r + 1 < 16 ? s[qb][0][r + 1] : s[qb][0][r]);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][1][r]), s[qb][1][r + 1]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      {   // max over the two lane halves through v_permlane32_swap_b32 (gfx950: lanes 32..63 of the first operand <-> lanes 0..31 of the second,
+          // inside the VALU) instead of __shfl_xor's ds_bpermute_b32: no LDS round trip in front of the branch below, twice per tile.  Inline asm:
+          // given the SAME value for both operands hipcc 7.2 folds the builtin's two results into one; the s_nop carry the VALU hazard slots
+        float lo_ = mt, hi_ = mt;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo_), "+v"(hi_));
+        mt = fmaxf(lo_, hi_);
+      }
       if (t == 0 || __builtin_amdgcn_ballot_w64(mt > ATTN_THR) != 0) {
         const float d = t == 0 ? mt : fmaxf(mt, 0.f);
         const float alpha = __builtin_amdgcn_exp2f(-d);
@@ -201,8 +228,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[qb][r] = -m_ref[qb];
       }
+    }
+    // ---- P = 2^S' and O^T += V^T · P^T, KEY HALF BY KEY HALF: the exponentials of half 1 are independent of the P·V MFMAs of half 0, so the
+    // quarter-rate v_exp_f32 of one half issue under the matrix pipe's work on the other (round 5: all 64 exponentials used to run back to back in
+    // front of all 24 MFMAs — 1024 cycles in which this wave kept the matrix pipe idle; interleaved: (64,10,4096,4096) 911 -> 940 TF/s, MFMA busy
+    // 0.566 -> 0.594, profiles/r05_attn_bench_*.log).  Same values, same accumulation order: torch.equal.
+    // The tile's row sums of P accumulate in `den`, which lives only here — every one of its rows is the sum for the lane's query.
+    auto exps = [&](const int i) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int qb = 0; qb < QW; ++qb)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           float e0 = __builtin_amdgcn_exp2f(s[qb][i][r]);
@@ -216,17 +250,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
           pf[qb][i][r >> 3][r & 7] = pk[0];
           pf[qb][i][r >> 3][(r & 7) + 1] = pk[1];
         }
-    }
-
-    // ---- O^T += V^T · P^T: each V^T fragment feeds two MFMAs; the tile's row sums of P accumulate in `den`, which lives only here
-    // (the score registers are dead by now) — every one of its rows is the sum for the lane's query
+    };
     f32x16 den[QW];
 #pragma unroll
     for (int qb = 0; qb < QW; ++qb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) den[qb][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    auto pv = [&](const int i) {
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
@@ -244,6 +274,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 #pragma unroll
         for (int qb = 0; qb < QW; ++qb) den[qb] = Vec<T>::mfma32(ones, pf[qb][i][k2], den[qb]);
       }
+    };
+    exps(0);
+    pv(0);
+    exps(1);      // (16 keys at a time instead of 32 was tried: 256 VGPRs + 36 bytes of scratch, and hipcc hoisted the exponentials anyway)
+    pv(1);
 #pragma unroll
     for (int qb = 0; qb < QW; ++qb) l_run[qb] += den[qb][0];
   };
