@@ -206,13 +206,15 @@ def _init(module, dev, seed, qk_gain=1.0):
         p.data.copy_(w.to(p.dtype))
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-2), (torch.bfloat16, 8e-2)])
-def test_full_width_transformer_block_matches_oracle(dev, dtype, tol):
-    """C = 1280, 20 heads, 32 x 32 tokens, context (77, 2048): the block that runs 60 times per SDXL forward."""
+@pytest.mark.parametrize("dtype,tol,N", [(torch.float16, 1.5e-2, 1024), (torch.bfloat16, 8e-2, 1024), (torch.float16, 1.5e-2, 1008)])
+def test_full_width_transformer_block_matches_oracle(dev, dtype, tol, N):
+    """C = 1280, 20 heads, 32 x 32 tokens, context (77, 2048): the block that runs 60 times per SDXL forward.  N = 1008 = 36 x 28: the deepest
+    level of a 1152 x 896 image (B3's height / width, lora_pipeline.py:217-218) — a ragged last key tile and a ragged query block in the
+    self-attention, a row count that is no multiple of 256 in every Linear."""
     from omg_amd.unet import BasicTransformerBlock
     blk = BasicTransformerBlock(1280, 20, 2048, dtype, dev)
     _init(blk, dev, 31)
-    B, N = 2, 1024
+    B = 2
     x = gen((B, N, 1280), dev, 32, dtype=dtype)
     ctx = gen((B, 77, 2048), dev, 33, dtype=dtype)
     y = blk(x, ctx, {}).float().cpu()
