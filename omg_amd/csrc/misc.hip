@@ -82,6 +82,63 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const char* X, int B, int
   }
 }
 
+// conv_out, round 5: ONE LANE PER OUTPUT PIXEL for the 16-bit UNet (Cout <= 4).  The kernel above gives a wave to every pixel and re-reads the lane's slice of
+// all the weights through the vector L1 for each of them (23 KB per pixel, 24 GB per launch: 1.9 ms for 671 MB of input, 14x its memory time — 0.5 % of the
+// benchmark step; round 5's first attempt, a per-wave pixel walk with the weight slice in registers, was twice as slow and is gone).  Here the weights are
+// WAVE-UNIFORM — every lane of a wave needs the same [co][tap][8 channels] vector at the same time — so they come through the scalar cache (s_load_dwordx4)
+// and feed v_dot2c_f32_{f16,bf16} as its SGPR operand: per (tap, 8 channels) one 16-byte vector load of the lane's own pixel and 16 dot2 instructions.  A lane
+// sweeps the 640 contiguous bytes of a neighbour pixel over 40 iterations (every 128-byte line is used whole before it leaves the L1); out-of-image taps load
+// the lane's own pixel and are zeroed by a select, so that control flow — and with it the scalar weight loads — stays uniform.  fp32 accumulation of exact
+// products in a fixed order: deterministic, batch-invariant; not bitwise the old kernel's summation order (tests compare with F.conv2d to 1e-4).
+template <typename T> struct Dot2;
+template <> struct Dot2<f16> {
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  static OMG_DEV float run(unsigned a, unsigned b, float c) { return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false); }
+};
+template <> struct Dot2<bf16> {
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  static OMG_DEV float run(unsigned a, unsigned b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false); }
+};
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void conv_out_pixel_kernel(const char* X, int B, int H, int W, int Cin, const char* Wt, const T* bias, float* Y) {
+  const long npix = (long)B * H * W;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = pix < npix;
+  const long pc = live ? pix : npix - 1;                 // dead lanes of the last block compute the last pixel and store nothing
+  const int b = (int)(pc / (H * W)); const int rem = (int)(pc - (long)b * H * W);
+  const int y = rem / W, x = rem - y * W;
+  const int nvec = Cin / 8;                              // a multiple of 4 (the launcher checks Cin % 32 == 0)
+  const long K2 = 9L * Cin * 2;                          // bytes per output channel of the weights [co][ky][kx][ci]
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+    const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+    const u32x4* px = (const u32x4*)(X + ((((long)b * H + (ok ? iy : y)) * W + (ok ? ix : x)) * Cin) * 2);
+    const char* wt = Wt + (long)tap * Cin * 2;
+    for (int v0 = 0; v0 < nvec; v0 += 4) {               // four 16-byte loads in flight per lane: 64 contiguous bytes of the pixel's channel vector
+      u32x4 xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = px[v0 + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok) xv[u] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+          const u32x4 wv = *(const u32x4*)(wt + co * K2 + (v0 + u) * 16);      // the same address in every lane: scalar cache
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[co] = Dot2<T>::run(xv[u][j], wv[j], acc[co]);
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int co = 0; co < CO; ++co) Y[(((long)b * CO + co) * H + y) * W + x] = acc[co] + (bias ? (float)bias[co] : 0.f);
+  }
+}
+
 // ------------------------------------------------- timestep embedding etc.
 // diffusers get_timestep_embedding(t, dim, flip_sin_to_cos=True, downscale_freq_shift=0):
 // out[i, j] = cos(t_i * f_j) for j < dim/2 ; sin(t_i * f_{j-dim/2}) otherwise; f_j = exp(-ln(10000) * j / (dim/2))
@@ -262,6 +319,12 @@ extern "C" int omg_conv_out(int dtype, const void* X, int B, int H, int W, int C
   if (npix == 0) return OMG_OK;
   long blocks = (npix + 3) / 4; if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
+  if (dtype != OMG_F32 && Cout == 4 && Cin % 32 == 0) {      // the 16-bit UNet's last convolution: one lane per pixel, weights through the scalar cache
+    const unsigned pb = (unsigned)((npix + 255) / 256);
+    if (dtype == OMG_F16) OMG_LAUNCH((conv_out_pixel_kernel<f16, 4>), dim3(pb), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Y);
+    else OMG_LAUNCH((conv_out_pixel_kernel<bf16, 4>), dim3(pb), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Y);
+    return omg_check_launch("conv_out_pixel");
+  }
   if (dtype == OMG_F16) OMG_LAUNCH(conv_out_kernel<f16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Cout, Y);
   else if (dtype == OMG_BF16) OMG_LAUNCH(conv_out_kernel<bf16>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Cout, Y);
   else OMG_LAUNCH(conv_out_kernel<float>, dim3(blocks), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const float*)bias, Cout, Y);
