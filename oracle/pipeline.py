@@ -11,8 +11,8 @@ Follows /root/reference ``src/pipelines/lora_pipeline.py``:
 
 PINNED (round 5) BY THE REFERENCE'S OWN LOOP RUN IN THE BUILD CONTAINER: tests/golden/make_golden_loop.py imports
 /root/reference/src/pipelines/lora_pipeline.py and instantid_pipeline.py unmodified under stand-in diffusers / torchvision modules and
-records the per-step latents of LoraMultiConceptPipeline.__call__ / InstantidMultiConceptPipeline.__call__ (seven cases: overlapping
-masks, a None mask, three concepts + styleL, non-square latents, a ControlNet, InstantID with / without the t2i ControlNet) in
+records the per-step latents of LoraMultiConceptPipeline.__call__ / InstantidMultiConceptPipeline.__call__ (ten cases: overlapping
+masks, a None mask, all masks None, one and three concepts, styleL, non-square latents, a ControlNet, InstantID with / without the t2i ControlNet) in
 tests/golden/loop_golden.npz; tests/test_oracle_loop.py reproduces them with `denoise` below — stage 1 bit-equal, stage 2 within one
 fp32 ulp.  (The reference ships no tests or recorded outputs of its own.)  float32 torch on CPU.
 """

@@ -382,7 +382,7 @@ def masks_for(H, W, kind):
     m1 = torch.zeros(H, W); m1[H // 4:, W // 16: W // 2 - 8] = 1
     m2 = torch.zeros(H, W); m2[H // 4:, W // 2 - 24: W - 8] = 1         # overlaps m1 (the sum rule of :603)
     m3 = torch.zeros(H, W); m3[: H // 3, W // 3:] = 1
-    return {"overlap": [m1, m2], "none_mid": [m1, None, m2], "three": [m1, m2, m3]}[kind]
+    return {"overlap": [m1, m2], "none_mid": [m1, None, m2], "three": [m1, m2, m3], "single": [m2], "all_none": [None, None]}[kind]
 
 
 CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, latent w), flow
@@ -390,6 +390,9 @@ CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, lat
     ("euler_none_mid", "euler", 20, 7.5, "none_mid", False, (16, 16), "lora"),
     ("ddim_style_three", "ddim", 18, 5.0, "three", True, (16, 16), "lora"),
     ("ddim_nonsquare", "ddim", 18, 7.5, "overlap", False, (24, 16), "lora"),
+    ("ddim_single_concept", "ddim", 18, 7.5, "single", False, (16, 16), "lora"),
+    ("euler_style_none_mid", "euler", 19, 3.0, "none_mid", True, (12, 20), "lora"),
+    ("ddim_all_masks_none", "ddim", 18, 7.5, "all_none", False, (16, 16), "lora"),       # no concept pass runs: stage 2 == stage 1 (nothing is pasted, :581)
     # lora_pipeline.py:519-566 with `image` given: a ControlNet on the four main rows, none on the concept rows
     ("ddim_controlnet", "ddim", 18, 7.5, "overlap", False, (16, 16), "lora_cn"),
     # instantid_pipeline.py:540-707: IdentityNet (key-point image + face tokens) and the IP-Adapter branch on the concept rows, guidance 3
@@ -590,7 +593,7 @@ def main():
         r = run_reference_instantid(c) if c["flow"].startswith("iid") else run_reference(c)
         for k, v in r.items():
             blob[f"{c['name']}/{k}"] = v
-        d = np.abs(r["stage2"][-1][1] - r["stage1"][-1][1]).max()
+        d = np.abs(r["stage2"][-1][1] - r["stage1"][-1][1]).max()      # (0 when every mask is None)
         print(f"{c['name']}: {c['steps']} steps, layers {int(r['num_att_layers'])}, stage-2 edit vs stage-1 max|d| = {d:.3f}, "
               f"base sample equal: {np.abs(r['stage2'][-1][0] - r['stage1'][-1][0]).max():.2e}")
     np.savez_compressed(os.path.join(HERE, "loop_golden.npz"), **blob)

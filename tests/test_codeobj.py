@@ -140,3 +140,35 @@ def test_the_row_major_v_attention_reads_v_through_the_transposing_lds_read(ks):
     for n, ins in _codeobj.disassembly(LIB, "attn_fwd_kernel7").items():
         assert ins.count("ds_read_b64_tr_b16") == 48 and ins.count("ds_read_b128") == 24, (n, ins.count("ds_read_b64_tr_b16"), ins.count("ds_read_b128"))
         assert ins.count("v_mov_b64_e32") <= 64 and ins.count("v_mov_b32_e32") <= 200, (n, ins.count("v_mov_b64_e32"), ins.count("v_mov_b32_e32"))
+
+
+def test_conv_out_pixel_kernel_takes_its_weights_through_the_scalar_cache(ks):
+    """conv_out_pixel_kernel (csrc/misc.hip, round 5): the design is that the wave-uniform weights never touch the vector memory path — scalar loads
+    feeding v_dot2c as its SGPR operand, 64 of them per four 16-byte loads of the lane's own pixel — at full occupancy (34 VGPRs, no scratch)."""
+    inst = pick(ks, "conv_out_pixel_kernel")
+    assert len(inst) == 2, list(inst)                    # f16 / bf16
+    for n, k in inst.items():
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 64, (n, k["vgpr_count"])
+    for n, ins in _codeobj.disassembly(LIB, "conv_out_pixel_kernel").items():
+        dots = sum(1 for x in ins if x.startswith("v_dot2c_f32_"))
+        assert dots == 64, (n, dots)                                                      # 4 vectors x 4 output channels x 4 dwords
+        assert sum(1 for x in ins if x.startswith("global_load_dwordx4")) == 4, n         # the pixel's channels only: no vector load of a weight
+        assert any(x.startswith("s_load_dwordx16") for x in ins), n                        # 64 contiguous weight bytes per output channel
+
+
+def test_the_generated_k_loop_schedule_is_what_the_generator_emits(tmp_path):
+    """omg_amd/csrc/gemm_v12_sched.inc is GENERATED (tools/gen_ksched.py) and committed so that hipcc needs no python at build time: the committed file
+    must be what the generator writes today."""
+    import importlib.util
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "repo"
+    (fake / "tools").mkdir(parents=True)
+    (fake / "omg_amd" / "csrc").mkdir(parents=True)
+    shutil.copy(os.path.join(root, "tools", "gen_ksched.py"), fake / "tools" / "gen_ksched.py")
+    spec = importlib.util.spec_from_file_location("gen_ksched_copy", str(fake / "tools" / "gen_ksched.py"))
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, str(fake / "tools" / "gen_ksched.py")], check=True, capture_output=True)
+    assert (fake / "omg_amd" / "csrc" / "gemm_v12_sched.inc").read_text() == open(os.path.join(root, "omg_amd", "csrc", "gemm_v12_sched.inc")).read()
+    assert spec is not None

@@ -107,7 +107,11 @@ def test_oracle_loop_matches_the_reference_pipeline_run_here(gold, case):
         assert err.max() < 2e-6 * max(1.0, rms), err            # measured: stage 1 bit-equal, stage 2 <= 7.6e-6 at latent rms 16
     s1, s2 = gold[f"{c['name']}/stage1"], gold[f"{c['name']}/stage2"]
     assert np.array_equal(s1[:16], s2[:16]), "stage 2 equals stage 1 until the first fused step (i > 15, lora_pipeline.py:568)"
-    assert np.abs(s2[-1][1] - s1[-1][1]).max() > 0.1 and np.array_equal(s2[:, 0], s1[:, 0])
+    assert np.array_equal(s2[:, 0], s1[:, 0]), "the base sample never depends on the edit"
+    if any(m is not None for m in c["masks"]):
+        assert np.abs(s2[-1][1] - s1[-1][1]).max() > 0.1
+    else:
+        assert np.array_equal(s2, s1), "all masks None: the union is empty, no concept pass runs, stage 2 is stage 1"
     # one set_adapters per concept at prompt encoding (:340-342) + one per concept WITH a mask per fused step (:588-591), both stages
     n_masked = sum(m is not None for m in c["masks"])
     fused = c["steps"] - 16
