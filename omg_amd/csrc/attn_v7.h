@@ -9,7 +9,7 @@
 // fragment instead of one ds_read_b128: the same bytes per lane, and the guide prices the transposing read at the plain b64's cost beside
 // MFMAs.  The key order the P registers dictate inside a group of 16 ([0-3, 8-11 | 4-7, 12-15] by lane half) is met by the ADDRESSES the
 // lanes supply, so no permuted image is needed either.
-// What is assumed about the instruction (cdna_hip_programming.md, LDS section + T10; tools/exp/tr16_probe.hip checks exactly this on the
+// What is assumed about the instruction (cdna_hip_programming.md, LDS section + T10; tools/ubench/tr16_probe.hip checked exactly this on the
 // part before the kernel is trusted): per group of 16 lanes, lane i supplies the address of 4 consecutive 16-bit elements = row (i >> 2),
 // columns 4 (i & 3) .. + 3 of a 4 x 16 block, and lane c receives column c (4 elements, row order).
 // Ragged last tile: the staged rows past Nkv repeat the last key (as K's do) — finite values, so the probabilities of those keys are set to

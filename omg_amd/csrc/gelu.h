@@ -31,7 +31,7 @@ OMG_DEV omg_f32x2 gelu_f2(omg_f32x2 x) {
   const omg_f32x2 h = {__builtin_amdgcn_exp2f(q1[0]), __builtin_amdgcn_exp2f(q1[1])};                    // erfc(|x| / sqrt 2) / 2
   // max(x, 0) on the BITS: a negative float is a negative integer (v_max_i32: one instruction; fmaxf canonicalises its operand first: two)
   // through scalar copies: __builtin_bit_cast applied to the vector ELEMENT x[1] read element 0 (hipcc 7.2: both maxima came out as max(x[0], 0) and
-  // the final v_pk_fma_f32 used r[0] for both halves — found in round 5 as 37 % wrong outputs of every large-tile GEGLU launch, tools/exp/gelu2_diag.py)
+  // the final v_pk_fma_f32 used r[0] for both halves — found in round 5 as 37 % wrong outputs of every large-tile GEGLU launch, a per-variant diff tool, profiles/r05_second_gelu2_diag.log)
   const float x0 = x[0], x1 = x[1];
   const int b0 = __builtin_bit_cast(int, x0), b1 = __builtin_bit_cast(int, x1);
   const int m0 = b0 > 0 ? b0 : 0, m1 = b1 > 0 ? b1 : 0;
