@@ -414,6 +414,17 @@ def main():
                     f.write(f"{key[0]:5s} {str(key[1]):56s} n={n:7.0f} ms={ms:9.2f} ({100 * ms / tot:4.1f}%) {fl / ms / 1e9 if ms else 0:7.1f} TF/s\n")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the host-core baseline is reported at N = 1 only
         out["cpu_baseline"] = cpu_baseline(args)
+        # BASELINE configs[0] — the reference's own CPU-runnable case (512^2, 10 DDIM steps, 1 concept, no LoRA) — timed FOR REAL at full width, no
+        # extrapolation: the oracle's 10-step stage-2 call on the GPU box's host cores (tests/test_config0_fullwidth_gpu.py, ~4 minutes per stage: too long
+        # for a default run, so the tracked measurement is quoted with its source; SURVEY §8(d) "time C1 end-to-end for real")
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_config0_fullwidth_loop.json")) as f:
+                c0 = json.load(f)
+            out["cpu_baseline_config0"] = dict(c0["cpu_baseline_config0"], source="profiles/r06_config0_fullwidth_loop.json (recorded by tests/test_config0_fullwidth_gpu.py "
+                                               "on a GPU box of this pool; not re-timed in this run)", hip_final_error_vs_fp32_oracle=c0["final"]["hip_vs_fp32_oracle"],
+                                               reference_fp16_arithmetic_vs_fp32_oracle=c0["final"]["fp16_oracle_vs_fp32_oracle"])
+        except (OSError, KeyError, ValueError):
+            pass
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_available() and torch.distributed.is_initialized():

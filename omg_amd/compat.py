@@ -287,7 +287,14 @@ class LoraMultiConceptPipeline(_PipeMixin, _LoraPipe):
         if image is not None:
             h = height or self.unet.config.sample_size * self.vae_scale_factor
             w = width or self.unet.config.sample_size * self.vae_scale_factor
-            image = _cond_image_tensor(image, h, w)
+            cn = kw.get("controlnet", self.controlnet)
+            n_nets = len(cn.nets) if hasattr(cn, "nets") else len(cn) if isinstance(cn, (list, tuple)) else 1
+            if n_nets > 1:      # a list of ControlNets (the reference wraps it in MultiControlNetModel, lora_pipeline.py:175-176): one image (or [img] * 2) per net
+                if not isinstance(image, (list, tuple)) or len(image) != n_nets:
+                    raise L.OmgHipError(f"{n_nets} ControlNets need a list of {n_nets} conditioning images (lora_pipeline.py:366-383)")
+                image = [_cond_image_tensor(im, h, w) for im in image]
+            else:
+                image = _cond_image_tensor(image, h, w)
         return _LoraPipe.__call__(self, prompt=prompt, prompt_2=prompt_2, image=image, height=height, width=width,
                                   output_type=output_type, return_dict=return_dict, **kw)
 

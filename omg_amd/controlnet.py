@@ -178,8 +178,6 @@ class ControlNetModel(nn.Module):
                 conditioning_scale: float = 1.0, class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
                 cross_attention_kwargs=None, guess_mode: bool = False, return_dict: bool = False,
                 emb: Optional[torch.Tensor] = None) -> Tuple[List[torch.Tensor], torch.Tensor]:
-        if guess_mode:
-            raise L.OmgHipError("guess_mode is never set by OMG's flows (global_pool_conditions is False) and is not supported")
         if not sample.is_cuda:
             raise L.OmgHipError("ControlNetModel runs on the MI355X only (no CPU fallback)")
         dt = self._dtype
@@ -208,10 +206,18 @@ class ControlNetModel(nn.Module):
         for blk in self.down_blocks:
             h = blk(h, ctx, kw, skips)
         h = self.mid_block(h, ctx, kw)
+        # guess_mode (diffusers ControlNetModel.forward "6. scaling", global_pool_conditions False; reached from lora_pipeline.py:519-528): the residuals
+        # are scaled by logspace(-1, 0, n + 1) * conditioning_scale — 0.1 for the shallowest skip ... 1.0 for the mid block — in the zero convolution's epilogue
+        scales = guess_mode_scales(len(skips), conditioning_scale) if guess_mode else [float(conditioning_scale)] * (len(skips) + 1)
         down = []
-        for zc, s in zip(self.controlnet_down_blocks, skips):
-            y = ops.conv2d(s, zc.packed_weight(), 1, bias=zc.bias, out_scale=conditioning_scale)
+        for zc, s, sc in zip(self.controlnet_down_blocks, skips, scales):
+            y = ops.conv2d(s, zc.packed_weight(), 1, bias=zc.bias, out_scale=sc)
             down.append(y.permute(0, 3, 1, 2))                 # NCHW-shaped view of NHWC storage (channels_last)
         mid = ops.conv2d(h, self.controlnet_mid_block.packed_weight(), 1, bias=self.controlnet_mid_block.bias,
-                         out_scale=conditioning_scale).permute(0, 3, 1, 2)
+                         out_scale=scales[-1]).permute(0, 3, 1, 2)
         return down, mid
+
+
+def guess_mode_scales(n_down: int, conditioning_scale: float) -> List[float]:
+    """``torch.logspace(-1, 0, n_down + 1) * conditioning_scale`` as diffusers computes it (fp32), as host floats for the epilogues' ``out_scale``."""
+    return [float(v) for v in (torch.logspace(-1, 0, n_down + 1, dtype=torch.float32) * float(conditioning_scale))]

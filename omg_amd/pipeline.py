@@ -38,6 +38,19 @@ FUSION_START = 15   # `if i > 15 and stage == 2` (lora_pipeline.py:568) — abso
 CONCEPT_LORA_SCALE = 0.8   # `cross_attention_kwargs={'scale': 0.8}` of every concept UNet call (lora_pipeline.py:596), whatever the caller passes
 
 
+def controlnet_keep(n_steps: int, start, end, n_nets: int = 1) -> List[List[float]]:
+    """``controlnet_keep`` of the reference (lora_pipeline.py:275-286 broadcast + :421-428): for step i and net k the factor on the conditioning scale is
+    1.0 while  start_k <= i / S  and  (i + 1) / S <= end_k,  else 0.0.  ``start`` / ``end``: scalars (every net) or one entry per net."""
+    def per_net(v, other):
+        if isinstance(v, (list, tuple)):
+            return [float(x) for x in v]
+        return [float(v)] * (len(other) if isinstance(other, (list, tuple)) else n_nets)
+    starts, ends = per_net(start, end), per_net(end, start)
+    if len(starts) != len(ends):
+        raise ValueError(f"control_guidance_start has {len(starts)} entries, control_guidance_end {len(ends)}")
+    return [[0.0 if (i / n_steps < s_ or (i + 1) / n_steps > e_) else 1.0 for s_, e_ in zip(starts, ends)] for i in range(n_steps)]
+
+
 def revise_regionally_controlnet_forward(unet, controller) -> None:
     """Install the region/controller attention processor on every ``Attention`` of the UNet and set
     ``controller.num_att_layers`` — same name, traversal order and place labels (including the
@@ -176,9 +189,6 @@ class StageCache:
 # default and that this engine does not implement: name -> (the default, where the reference uses it).  A non-default value is REFUSED — ignoring
 # it would return an image the reference would not have produced, without a word.
 _UNIMPLEMENTED = {
-    "guess_mode": (False, "lora_pipeline.py:236, :497-503 (ControlNet on the conditional rows only)"),
-    "control_guidance_start": (0.0, "lora_pipeline.py:237, :421-428 (controlnet_keep)"),
-    "control_guidance_end": (1.0, "lora_pipeline.py:238, :421-428 (controlnet_keep)"),
     "callback": (None, "lora_pipeline.py:256, :629-632"), "callback_steps": (None, "lora_pipeline.py:257"),
     "callback_on_step_end": (None, "lora_pipeline.py:246, :617-626"),
     "prompt_2": (None, "lora_pipeline.py:215 (second text encoder's own prompt)"), "negative_prompt_2": (None, "lora_pipeline.py:222"),
@@ -270,14 +280,23 @@ class LoraMultiConceptPipeline:
                  lora_mode: str = "merged", dedup: bool = False, **kwargs):
         controlnet = kwargs.pop("controlnet", getattr(self, "controlnet", None))
         cn_scale = kwargs.pop("controlnet_conditioning_scale", 1.0)
+        # round 6: implemented instead of refused (lora_pipeline.py:236-238; generate_many's docstring)
+        guess_mode = bool(kwargs.pop("guess_mode", False))
+        cg_start, cg_end = kwargs.pop("control_guidance_start", 0.0), kwargs.pop("control_guidance_end", 1.0)
         stage_cache, drop_unc0 = kwargs.pop("stage_cache", None), kwargs.pop("drop_unc0", False)
         given = {k: kwargs.pop(k) for k in list(kwargs) if k in _UNIMPLEMENTED}
         given.update(prompt_2=prompt_2, negative_prompt_2=negative_prompt_2, num_images_per_prompt=num_images_per_prompt)
         refuse_unimplemented(given, kwargs, "LoraMultiConceptPipeline.__call__")
-        if isinstance(cn_scale, (list, tuple)):          # lora_pipeline.py:513-515: one ControlNet takes the first entry
-            cn_scale = cn_scale[0]
-        if isinstance(image, (list, tuple)) and image is not None and len(image) != 1:
-            raise L.OmgHipError("a list of ControlNet images (MultiControlNetModel, lora_pipeline.py:171-172) is not implemented: pass one image")
+        n_nets = len(controlnet.nets) if hasattr(controlnet, "nets") else len(controlnet) if isinstance(controlnet, (list, tuple)) else 1
+        if n_nets == 1:
+            if isinstance(cn_scale, (list, tuple)):      # lora_pipeline.py:513-515: one ControlNet takes the first entry
+                cn_scale = cn_scale[0]
+            if isinstance(image, (list, tuple)):         # a one-element list reached generate_many un-unwrapped
+                if len(image) != 1:
+                    raise L.OmgHipError(f"{len(image)} ControlNet images for one ControlNet: pass one image, or a list of ControlNets (lora_pipeline.py:175-176)")
+                image = image[0]
+        elif image is not None and (not isinstance(image, (list, tuple)) or len(image) != n_nets):
+            raise L.OmgHipError(f"{n_nets} ControlNets need a list of {n_nets} conditioning images (lora_pipeline.py:366-383)")
         if image is not None and controlnet is None:
             raise L.OmgHipError("image= needs a ControlNet: pass controlnet=omg_amd.controlnet.ControlNetModel(...)")
         if eta != 0.0:
@@ -318,7 +337,8 @@ class LoraMultiConceptPipeline:
                                  controller=controller, concept_models=concept_models, stage=stage, lora_list=lora_list,
                                  styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
                                  lora_mode=lora_mode, controlnet=controlnet if image is not None else None, controlnet_image=image,
-                                 controlnet_conditioning_scale=cn_scale, dedup=dedup, stage_cache=stage_cache, drop_unc0=drop_unc0)[0]
+                                 controlnet_conditioning_scale=cn_scale, dedup=dedup, stage_cache=stage_cache, drop_unc0=drop_unc0,
+                                 guess_mode=guess_mode and image is not None, control_guidance_start=cg_start, control_guidance_end=cg_end)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         images = self._postprocess(lat, output_type)
@@ -358,7 +378,8 @@ class LoraMultiConceptPipeline:
                       concept_lora: bool = True, concept_shard=None,
                       main_adapters: Optional[Sequence[Tuple[str, float]]] = None,
                       concept_adapters: Optional[Sequence[Tuple[str, float]]] = None, concept_adapter_scale: float = 1.0,
-                      stage_cache: Optional[StageCache] = None, drop_unc0: bool = False) -> torch.Tensor:
+                      stage_cache: Optional[StageCache] = None, drop_unc0: bool = False, guess_mode: bool = False,
+                      control_guidance_start=0.0, control_guidance_end=1.0) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -366,6 +387,13 @@ class LoraMultiConceptPipeline:
 
         ``controlnet`` + ``controlnet_image`` (1|n,3,H,W in [0,1]): ControlNet on the MAIN pass of every step
         (lora_pipeline.py:519-536; ``controlnet2``/``t2i_image`` of instantid_pipeline.py:574-592).
+        Round 6: ``controlnet`` may be a LIST of ControlNets (or an object with ``.nets``: the reference wraps a list in diffusers' MultiControlNetModel,
+        lora_pipeline.py:175-176) with a list of images and of scales — every net sees its own image at its own scale, the residuals are summed in list
+        order (:366-383, :511-512); ``control_guidance_start`` / ``_end`` (scalars or one per net) give ``controlnet_keep[i]`` — the per-step factor 0 / 1 on
+        the conditioning scale (:275-286, :421-428, :511-517; a net whose factor is 0 in a step is not run: adding its zero residuals = not adding them),
+        for the IdentityNet and the t2i ControlNet of the InstantID flow too (instantid_pipeline.py:477-483, :566-578); ``guess_mode=True``
+        (:497-503, :531-535): the nets see only the CONDITIONAL rows ``[cond0, cond1]`` of every request, with diffusers' logspace residual scaling, and the
+        unconditional rows get no residual.
         ``identitynet`` (InstantID, instantid_pipeline.py:638-674): ControlNet on the CONCEPT pass fed with the face tokens and
         the request's ``kps_image`` (1,3,H,W); requests then also carry ``region_image_embeds`` = [(2,16,Cx) [zero-id, id]] * K and
         the UNet must have an :class:`omg_amd.ip_adapter.IPAdapter` installed.
@@ -407,6 +435,26 @@ class LoraMultiConceptPipeline:
         original_size = original_size or (height, width)
         target_size = target_size or (height, width)
         Cl = self.unet.config.in_channels
+        # ---- ControlNet plan: one net without guess_mode runs on the engine's original single-net path (twin / shard / stage-cache aware); a list of
+        # nets or guess_mode on the general path `cn_multi` below (full batch only)
+        cn_multi = None
+        n_cn = 0
+        if controlnet is not None:
+            nets = list(controlnet.nets) if hasattr(controlnet, "nets") else list(controlnet) if isinstance(controlnet, (list, tuple)) else [controlnet]
+            imgs = list(controlnet_image) if isinstance(controlnet_image, (list, tuple)) else [controlnet_image]
+            scs = list(controlnet_conditioning_scale) if isinstance(controlnet_conditioning_scale, (list, tuple)) else [controlnet_conditioning_scale] * len(nets)
+            if not nets or len(imgs) != len(nets) or len(scs) < len(nets) or any(im is None for im in imgs):
+                raise ValueError(f"{len(nets)} ControlNet(s) need as many conditioning images and scales (got {len(imgs)} image(s), {len(scs)} scale(s))")
+            n_cn = len(nets)
+            if n_cn == 1 and not guess_mode:
+                controlnet, controlnet_image, controlnet_conditioning_scale = nets[0], imgs[0], float(scs[0])
+            else:
+                cn_multi = SimpleNamespace(nets=nets, images=imgs, scales=[float(x) for x in scs[:n_cn]], guess=bool(guess_mode))
+                controlnet, controlnet_image, controlnet_conditioning_scale = None, None, 1.0
+        # controlnet_keep (lora_pipeline.py:421-428): per step, per net, 0.0 or 1.0
+        cn_keep = controlnet_keep(S, control_guidance_start, control_guidance_end, max(1, n_cn))
+        if len(cn_keep[0]) != max(1, n_cn):
+            raise ValueError(f"control_guidance_start / _end must be scalars or hold one entry per ControlNet ({max(1, n_cn)})")
         # ---- per-request tensors
         lats, ehs_l, text_l, masks_l, cehs_l, ctext_l, ip_l, kps_l = [], [], [], [], [], [], [], []
         active = None
@@ -444,6 +492,10 @@ class LoraMultiConceptPipeline:
                     kps_l.append(r["kps_image"].to(device=dev, dtype=torch.float32))
         Ka = len(active)
         shard = concept_shard if (concept_shard is not None and concept_shard.world > 1) else None
+        if cn_multi is not None:
+            if shard is not None:
+                raise L.OmgHipError("concept_shard with a list of ControlNets / guess_mode is not built: run the unsharded call")
+            dedup, stage_cache, drop_unc0 = False, None, False        # the general ControlNet path runs the full batch
         twin = bool(dedup) and shard is None and (controller is None or getattr(controller, "is_pure_replacement", False))
         if twin and controlnet is not None and controlnet_image is not None and controlnet_image.shape[0] not in (1, n):
             twin = False      # one conditioning image per MAIN ROW (4n): the two samples of a request may differ, and the 2n-row twin batch
@@ -540,7 +592,8 @@ class LoraMultiConceptPipeline:
                       id(self.unet), getattr(self.unet, "weights_version", 0), getattr(bank, "version", None) if main_adapters else None,
                       None if controller is None else (type(controller).__name__, getattr(controller, "is_pure_replacement", False),
                                                        getattr(controller, "num_self_replace", None)),
-                      None if not use_cn else (id(controlnet), getattr(controlnet, "weights_version", 0), float(controlnet_conditioning_scale)))
+                      None if not use_cn else (id(controlnet), getattr(controlnet, "weights_version", 0), float(controlnet_conditioning_scale),
+                                               tuple(k[0] for k in cn_keep[: fusion_start + 1])))
             coef_key = self.scheduler.coef_table(dev)
             for j in range(n):
                 cn_img = None if not use_cn else (controlnet_image if controlnet_image.shape[0] == 1 else controlnet_image[j: j + 1])
@@ -566,7 +619,8 @@ class LoraMultiConceptPipeline:
                str(dt), batched, bool(styleL), tuple(main_adapters), tuple(concept_adapters), float(concept_adapter_scale), main_scale,
                tuple(lora_list), mshape, tuple(ehs.shape), id(controller), id(controlnet), id(identitynet),
                float(controlnet_conditioning_scale), float(identitynet_conditioning_scale), twin,
-               (shard.rank, shard.world) if shard is not None else None, drop0)
+               (shard.rank, shard.world) if shard is not None else None, drop0,
+               None if cn_multi is None else (tuple(id(x) for x in cn_multi.nets), tuple(tuple(im.shape) for im in cn_multi.images), cn_multi.guess))
         eng = self._engines.pop(key, None)
         if eng is not None:
             self._engines[key] = eng                       # most recently used last
@@ -602,6 +656,14 @@ class LoraMultiConceptPipeline:
                 eng.cn_image = torch.empty((controlnet_image.shape[0], 3, height, width), dtype=torch.float32, device=dev)
                 eng.cn_emb = torch.empty((S, nm, D), dtype=dt, device=dev)
                 eng.cn_emb_cur = torch.empty((nm, D), dtype=dt, device=dev)
+            if cn_multi is not None:
+                rows_cn = 2 * n if cn_multi.guess else nm
+                eng.cnm_image = [torch.empty((im.shape[0], 3, height, width), dtype=torch.float32, device=dev) for im in cn_multi.images]
+                eng.cnm_emb = [torch.empty((S, rows_cn, D), dtype=dt, device=dev) for _ in cn_multi.nets]
+                eng.cnm_emb_cur = [torch.empty((rows_cn, D), dtype=dt, device=dev) for _ in cn_multi.nets]
+                if cn_multi.guess:      # the conditional rows [cond0, cond1] of every request, compact
+                    eng.cnm_x = torch.empty((rows_cn, Cl, Hl, Wl), dtype=dt, device=dev)
+                    eng.cnm_ehs = torch.empty((rows_cn,) + tuple(ehs.shape[1:]), dtype=dt, device=dev)
             if use_idn:
                 eng.ip_all = torch.empty((ncn,) + tuple(ip_l[0].shape[1:]), dtype=dt, device=dev)
                 eng.kps_all = torch.empty((n, 3, height, width), dtype=torch.float32, device=dev)
@@ -644,7 +706,7 @@ class LoraMultiConceptPipeline:
                                   f"{self.max_engines} call shapes alternate and each eviction re-captures its hipGraphs; raise pipe.max_engines")
             self._engines[key] = eng
             # the key holds id()s: keep the objects alive so that an id cannot be recycled for a different object
-            eng.refs = (controller, controlnet, identitynet, concept_models)
+            eng.refs = (controller, controlnet, identitynet, concept_models, cn_multi.nets if cn_multi is not None else None)
             eng.epoch = pointer_epoch()
         # ---- load this call's inputs into the static buffers (device-to-device copies; graphs keep their pointers)
         lat = eng.lat
@@ -691,6 +753,19 @@ class LoraMultiConceptPipeline:
             eng.cn_image.copy_(controlnet_image.to(device=dev, dtype=torch.float32))
             t_all = ts.reshape(S, 1).expand(S, nm).reshape(-1).contiguous()
             eng.cn_emb.copy_(controlnet.time_embed(t_all, S * nm, torch.cat(text_l, dim=0).repeat(S, 1), tids_m.repeat(S, 1)).view(S, nm, D))
+        if cn_multi is not None:
+            cond_rows = torch.tensor([4 * j + r for j in range(n) for r in (2, 3)], dtype=torch.long, device=dev)
+            text_cn, tids_cn, rows_cn = torch.cat(text_l, dim=0), tids_m, nm
+            if cn_multi.guess:      # add_text_embeds.chunk(2)[1] / add_time_ids.chunk(2)[1] / prompt_embeds.chunk(2)[1] (lora_pipeline.py:497-503)
+                text_cn, tids_cn, rows_cn = text_cn.index_select(0, cond_rows), tids_m.index_select(0, cond_rows), 2 * n
+                eng.cnm_ehs.copy_(ehs.index_select(0, cond_rows))
+            t_all = ts.reshape(S, 1).expand(S, rows_cn).reshape(-1).contiguous()
+            for k_, net in enumerate(cn_multi.nets):
+                eng.cnm_image[k_].copy_(cn_multi.images[k_].to(device=dev, dtype=torch.float32))
+                eng.cnm_emb[k_].copy_(net.time_embed(t_all, S * rows_cn, text_cn.repeat(S, 1), tids_cn.repeat(S, 1)).view(S, rows_cn, D))
+                if use_graph:
+                    net.refresh_cross_kv(eng.cnm_ehs if cn_multi.guess else eng.ehs)
+                    net.cond_features(eng.cnm_image[k_])
         if use_idn:
             eng.ip_all.copy_(torch.cat(ip_l, dim=0))
             eng.kps_all.copy_(torch.cat(kps_l, dim=0))
@@ -742,6 +817,42 @@ class LoraMultiConceptPipeline:
                 identitynet.cond_features(eng.kps_all)
                 self.unet.refresh_ip_kv(eng.ip_all)      # the UNet's own image-prompt K / V^T of the concept samples
 
+        # the conditioning scales of the CURRENT step (host floats baked into the zero convolutions' epilogues, hence part of the graph regime):
+        # scale * controlnet_keep[i] (lora_pipeline.py:511-517; instantid_pipeline.py:566-578: the one window scales the IdentityNet and the t2i net)
+        cur = SimpleNamespace(cn=float(controlnet_conditioning_scale), idn=float(identitynet_conditioning_scale), multi=())
+
+        def set_step_scales(i: int) -> tuple:
+            k0 = cn_keep[i][0]
+            cur.cn, cur.idn = float(controlnet_conditioning_scale) * k0, float(identitynet_conditioning_scale) * k0
+            if cn_multi is not None:
+                cur.multi = tuple(sc * cn_keep[i][k_] for k_, sc in enumerate(cn_multi.scales))
+            return (cur.cn if use_cn else None, cur.idn if use_idn else None, cur.multi)
+
+        def multi_residuals():
+            """The general ControlNet block of a step: every net of the list on the main rows (guess_mode: on the conditional rows only), residuals
+            summed in list order like MultiControlNetModel.forward — first the nets' residuals among themselves, then onto the skips — and, in
+            guess_mode, no residual for the unconditional rows (lora_pipeline.py:531-535 concatenates zeros)."""
+            sum_d = sum_m = None
+            if cn_multi.guess:
+                eng.cnm_x.view(n, 2, Cl, Hl, Wl).copy_(xin[:nm].view(n, 4, Cl, Hl, Wl)[:, 2:4])
+            for k_, net in enumerate(cn_multi.nets):
+                sc = cur.multi[k_]
+                if sc == 0.0:
+                    continue
+                ops.gather_step(eng.cnm_emb[k_], step_idx, eng.cnm_emb_cur[k_])
+                d_, m_ = net(eng.cnm_x if cn_multi.guess else xin[:nm], None, encoder_hidden_states=eng.cnm_ehs if cn_multi.guess else eng.ehs,
+                             controlnet_cond=eng.cnm_image[k_], conditioning_scale=sc, emb=eng.cnm_emb_cur[k_], guess_mode=cn_multi.guess)
+                if sum_d is None:
+                    sum_d, sum_m = d_, m_
+                else:
+                    for a_, b_ in zip(sum_d + [sum_m], d_ + [m_]):
+                        ops.add_(a_.permute(0, 2, 3, 1), b_.permute(0, 2, 3, 1))
+            if sum_d is None:
+                return []
+            if not cn_multi.guess:
+                return [(0, nm, sum_d, sum_m)]
+            return [(4 * j + 2, 4 * j + 4, [d_[2 * j: 2 * j + 2] for d_ in sum_d], sum_m[2 * j: 2 * j + 2]) for j in range(n)]
+
         def region_rows(j):
             return nm + 2 * Ka * j
 
@@ -757,10 +868,10 @@ class LoraMultiConceptPipeline:
             kw["omg_twin"] = True
             x2, y2 = eng.xin2, eng.nout2
             x2.view(n, 2, Cl, Hl, Wl).copy_(xin[:nm].view(n, 2, 2, Cl, Hl, Wl)[:, :, 0])
-            if use_cn:
+            if use_cn and cur.cn != 0.0:
                 ops.gather_step(eng.cn_emb2, step_idx, eng.cn_emb_cur2)
                 d_, m_ = controlnet(x2, None, encoder_hidden_states=eng.ehs2, controlnet_cond=eng.cn_image,
-                                    conditioning_scale=controlnet_conditioning_scale, emb=eng.cn_emb_cur2)
+                                    conditioning_scale=cur.cn, emb=eng.cn_emb_cur2)
                 kw["omg_residuals"] = [(0, 2 * n, d_, m_)]
             ops.gather_step(eng.emb_main2, step_idx, eng.emb_cur2)
             self.unet.set_lora_state(state_twin)
@@ -780,18 +891,21 @@ class LoraMultiConceptPipeline:
                 return twin_body()
             kw = dict(main_kw)
             residuals = []
-            if use_cn:                                    # ControlNet on the main samples (lora_pipeline.py:519-536)
+            if use_cn and cur.cn != 0.0:                  # ControlNet on the main samples (lora_pipeline.py:519-536); scale 0 = outside its guidance window
                 ops.gather_step(eng.cn_emb, step_idx, eng.cn_emb_cur)
                 d_, m_ = controlnet(xin[:nm], None, encoder_hidden_states=eng.ehs, controlnet_cond=eng.cn_image,
-                                    conditioning_scale=controlnet_conditioning_scale, emb=eng.cn_emb_cur)
+                                    conditioning_scale=cur.cn, emb=eng.cn_emb_cur)
                 residuals.append((0, nm, d_, m_))
+            if cn_multi is not None:
+                residuals.extend(multi_residuals())
             if fused and batched:
                 fill_region_inputs()
                 if use_idn:                               # IdentityNet on the concept samples (instantid_pipeline.py:638-648)
-                    ops.gather_step(eng.idn_emb, step_idx, eng.idn_emb_cur)
-                    d_, m_ = identitynet(xin[nm:], None, encoder_hidden_states=eng.ip_all, controlnet_cond=eng.kps_all,
-                                         conditioning_scale=identitynet_conditioning_scale, emb=eng.idn_emb_cur)
-                    residuals.append((nm, nb, d_, m_))
+                    if cur.idn != 0.0:
+                        ops.gather_step(eng.idn_emb, step_idx, eng.idn_emb_cur)
+                        d_, m_ = identitynet(xin[nm:], None, encoder_hidden_states=eng.ip_all, controlnet_cond=eng.kps_all,
+                                             conditioning_scale=cur.idn, emb=eng.idn_emb_cur)
+                        residuals.append((nm, nb, d_, m_))
                     kw["omg_ip_tokens"], kw["omg_ip_rows"] = eng.ip_all, nm
                 if residuals:
                     kw["omg_residuals"] = residuals
@@ -836,10 +950,10 @@ class LoraMultiConceptPipeline:
             if drop0:
                 kw["omg_main_batch"] = 3                  # [unc1, cond0, cond1]: cond1 borrows Q, K of cond0 = row 1 of the block
             sh.x.copy_(xin[:nm].index_select(0, sh.src))
-            if use_cn and sh.n_main:
+            if use_cn and sh.n_main and cur.cn != 0.0:
                 ops.gather_step(sh.cn_emb, step_idx, sh.cn_emb_cur)
                 d_, m_ = controlnet(sh.x[: sh.n_main], None, encoder_hidden_states=sh.ehs[: sh.n_main], controlnet_cond=sh.cn_image,
-                                    conditioning_scale=controlnet_conditioning_scale, emb=sh.cn_emb_cur)
+                                    conditioning_scale=cur.cn, emb=sh.cn_emb_cur)
                 kw["omg_residuals"] = [(0, sh.n_main, d_, m_)]
             ops.gather_step(sh.emb, step_idx, sh.emb_cur)
             self.unet.set_lora_state(sh.state)
@@ -851,10 +965,11 @@ class LoraMultiConceptPipeline:
         def run_step(i: int):
             fused = fuse_possible and i > fusion_start
             tw = twin and not fused          # the samples part ways at the first fused step (stage 1: never)
+            scales_i = set_step_scales(i)
             if shard is not None:
                 sh = eng.sh[fused]
                 if sh.rows:
-                    run_forward(shard_forward, fused, False, ("shard", fused))
+                    run_forward(shard_forward, fused, False, ("shard", fused, scales_i))
                 elif controller is not None:
                     controller.cur_step += 1          # no unit of this step is ours: only the host-side step counter moves
                 shard.exchange(sh.y, sh.counts, sh.dsts, nout)
@@ -865,7 +980,7 @@ class LoraMultiConceptPipeline:
                     if i + 1 < S:
                         xin[:nm].view(n, 4, Cl, Hl, Wl)[:, 2].copy_(bx)
                 return
-            run_forward(step_body, fused, tw, (fused,))
+            run_forward(step_body, fused, tw, (fused, scales_i))
 
         def run_forward(body, fused: bool, tw: bool, tag: tuple):
             if not use_graph:
@@ -936,7 +1051,9 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                  concept_models: Optional[ConceptModels] = None, stage: Optional[int] = None, region_masks=None,
                  region_prompt_embeds=None, region_image_embeds=None, output_type: str = "pil", return_dict: bool = True,
                  use_graph: bool = False, trajectory: Optional[list] = None, fusion_start: int = FUSION_START, dedup: bool = False,
-                 cross_attention_kwargs=None, main_adapters=None, concept_adapters=None, lora_mode: str = "merged", **kwargs):
+                 cross_attention_kwargs=None, main_adapters=None, concept_adapters=None, lora_mode: str = "merged", eta: float = 0.0,
+                 original_size=None, crops_coords_top_left=(0, 0), target_size=None, guess_mode: bool = False,
+                 control_guidance_start=0.0, control_guidance_end=1.0, **kwargs):
         """``main_adapters`` / ``concept_adapters`` [(name, weight)]: LoRA adapters of ``concept_models.bank`` that PEFT would have active
         on the main / the concept pipe (inference_instantid.py:220-222 loads a style LoRA into both; nothing deactivates it).  The main
         UNet is called with ``cross_attention_kwargs`` (its ``"scale"`` is the LoRA scale, :596-616), the concept UNet with
@@ -944,6 +1061,14 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
         if prompt_embeds is None:
             raise L.OmgHipError("pass prompt_embeds=/pooled_prompt_embeds= (text encoders are outside this package's scope)")
         stage_cache = kwargs.pop("stage_cache", None)
+        if eta != 0.0:
+            raise L.OmgHipError("eta != 0 (stochastic DDIM) is not used by OMG and is not supported")
+        if guess_mode:
+            # the reference's OWN InstantID loop cannot run it: the IdentityNet is fed the two concept rows and its residuals are then concatenated with
+            # zeros to FOUR rows for a two-row concept UNet (instantid_pipeline.py:638-657), and the t2i net's two-row residuals meet the four-row main
+            # UNet without that concatenation (:580-616) — a shape error either way.  The LoRA flow's guess_mode is implemented (generate_many).
+            raise L.OmgHipError("guess_mode=True: the reference's InstantID loop itself fails on it (residual batch 4 vs 2, instantid_pipeline.py:638-657); "
+                                "LoraMultiConceptPipeline implements it")
         for dead in ("face_app", "prompt", "negative_prompt"):      # consumed by omg_amd.compat's front end when the scripts call it; dead here
             kwargs.pop(dead, None)
         refuse_unimplemented({k: kwargs.pop(k) for k in list(kwargs) if k in _UNIMPLEMENTED}, kwargs, "InstantidMultiConceptPipeline.__call__")
@@ -964,7 +1089,8 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                                  controlnet_conditioning_scale=t2i_controlnet_conditioning_scale, dedup=dedup, concept_lora=False,
                                  cross_attention_kwargs=cross_attention_kwargs, main_adapters=main_adapters,
                                  concept_adapters=concept_adapters, concept_adapter_scale=1.0, lora_mode=lora_mode,
-                                 stage_cache=stage_cache)[0]
+                                 stage_cache=stage_cache, original_size=original_size, crops_coords_top_left=crops_coords_top_left,
+                                 target_size=target_size, control_guidance_start=control_guidance_start, control_guidance_end=control_guidance_end)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         lat = self._postprocess(lat, output_type)

@@ -78,7 +78,10 @@ def cond_embedding(sd, cond: torch.Tensor) -> torch.Tensor:
 
 
 def controlnet_forward(sd, cfg: ou.UNetConfig, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale,
-                       text_embeds, time_ids, attn_fn: ou.AttnFn = ou.plain_attention) -> Tuple[List[torch.Tensor], torch.Tensor]:
+                       text_embeds, time_ids, attn_fn: ou.AttnFn = ou.plain_attention, guess_mode: bool = False) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    """``guess_mode`` (diffusers 0.25.0 ControlNetModel.forward, "6. scaling", with ``global_pool_conditions`` False — recalled, third-party): the
+    residuals are scaled by ``logspace(-1, 0, n_down + 1) * conditioning_scale`` (0.1 for the shallowest skip ... 1.0 for the mid block) instead of
+    by ``conditioning_scale`` alone.  Reached from lora_pipeline.py:519-528 when the caller passes ``guess_mode=True``."""
     B = sample.shape[0]
     t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1)
     if t.numel() == 1:
@@ -105,7 +108,13 @@ def controlnet_forward(sd, cfg: ou.UNetConfig, sample, timestep, encoder_hidden_
     h = ou.resnet_block(sd, "mid_block.resnets.0", cfg, h, emb)
     h = ou.transformer_2d(sd, "mid_block.attentions.0", cfg, cfg.attention_head_dim[-1], cfg.transformer_layers_per_block[-1], h, ctx, attn_fn)
     h = ou.resnet_block(sd, "mid_block.resnets.1", cfg, h, emb)
-    down = [F.conv2d(s, sd[f"controlnet_down_blocks.{i}.weight"], sd[f"controlnet_down_blocks.{i}.bias"]) * conditioning_scale
+    scales = guess_mode_scales(len(skips), conditioning_scale) if guess_mode else [conditioning_scale] * (len(skips) + 1)
+    down = [F.conv2d(s, sd[f"controlnet_down_blocks.{i}.weight"], sd[f"controlnet_down_blocks.{i}.bias"]) * scales[i]
             for i, s in enumerate(skips)]
-    mid = F.conv2d(h, sd["controlnet_mid_block.weight"], sd["controlnet_mid_block.bias"]) * conditioning_scale
+    mid = F.conv2d(h, sd["controlnet_mid_block.weight"], sd["controlnet_mid_block.bias"]) * scales[-1]
     return down, mid
+
+
+def guess_mode_scales(n_down: int, conditioning_scale: float) -> List[float]:
+    """``torch.logspace(-1, 0, n_down + 1) * conditioning_scale`` (fp32, as diffusers computes it)"""
+    return [float(v) for v in (torch.logspace(-1, 0, n_down + 1) * conditioning_scale)]

@@ -86,3 +86,45 @@ def denoise(main_unet: Callable, concept_unets: Sequence[Optional[Callable]], sc
         if record is not None:
             record.append(latents.clone())
     return latents
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ControlNet call pattern on the MAIN rows (lora_pipeline.py:275-286, :421-428, :497-536; twin instantid_pipeline.py:477-483, :552-589)
+
+
+def controlnet_keep(n_steps: int, control_guidance_start, control_guidance_end, n_nets: int = 1):
+    """lora_pipeline.py:275-286 (scalars broadcast to one entry per ControlNet) + :421-428: ``keep[i][k] = 1 - float(i / S < start_k or (i + 1) / S > end_k)``.
+    Returns a list over steps of lists over nets (the reference collapses the inner list to a scalar for a single ControlNetModel)."""
+    s, e = control_guidance_start, control_guidance_end
+    if not isinstance(s, list) and isinstance(e, list):
+        s = len(e) * [s]
+    elif not isinstance(e, list) and isinstance(s, list):
+        e = len(s) * [e]
+    elif not isinstance(s, list) and not isinstance(e, list):
+        s, e = n_nets * [s], n_nets * [e]
+    return [[1.0 - float(i / n_steps < s_ or (i + 1) / n_steps > e_) for s_, e_ in zip(s, e)] for i in range(n_steps)]
+
+
+def main_controlnet_residuals(nets: Sequence[Callable], x4: torch.Tensor, i: int, ctx4: torch.Tensor, te4: torch.Tensor, tid4: torch.Tensor,
+                              images: Sequence[torch.Tensor], scales: Sequence[float], keep_i: Sequence[float], guess_mode: bool = False):
+    """The ControlNet block of one iteration (lora_pipeline.py:497-536) for ONE net or a MultiControlNetModel (diffusers: the nets' residuals are summed
+    in list order).  ``nets[k](x, i, ctx, image, scale, te, tid, guess_mode) -> (down[9], mid)``; ``x4`` = the scaled ``[unc0, unc1, cond0, cond1]`` input.
+    guess_mode (:497-503, :531-535): the nets see only the CONDITIONAL half — ``scale_model_input(latents)`` is rows 2, 3 of x4, the positive prompt
+    embeddings, ``add_text_embeds.chunk(2)[1]``, an image that ``prepare_image`` did not duplicate — and zeros are concatenated in front for the
+    unconditional rows.  ``images[k]`` is (1, 3, H, W)."""
+    down = mid = None
+    for k, net in enumerate(nets):
+        sc = scales[k] * keep_i[k]                                            # :511-517
+        if guess_mode:
+            d, m = net(x4[2:4], i, ctx4[2:4], images[k].repeat(2, 1, 1, 1), sc, te4[2:4], tid4[2:4], True)
+        else:
+            d, m = net(x4, i, ctx4, images[k].repeat(4, 1, 1, 1), sc, te4, tid4, False)
+        if down is None:
+            down, mid = list(d), m
+        else:                                                                 # MultiControlNetModel.forward: samples_prev + samples_curr
+            down = [a + b for a, b in zip(down, d)]
+            mid = mid + m
+    if guess_mode:                                                            # :531-535
+        down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+        mid = torch.cat([torch.zeros_like(mid), mid])
+    return down, mid

@@ -120,25 +120,47 @@ class StubPipelineBase:
 
 
 class StubControlNetModel(nn.Module):
-    """diffusers ControlNetModel's call contract (lora_pipeline.py:519-536) over the oracle's functional ControlNet (oracle/controlnet.py)."""
+    """diffusers ControlNetModel's call contract (lora_pipeline.py:519-536) over the oracle's functional ControlNet (oracle/controlnet.py);
+    ``guess_mode`` = diffusers' logspace residual scaling (restated in oracle/controlnet.py, third-party arithmetic)."""
     config = _Cfg(global_pool_conditions=False)
     dtype = torch.float32
 
     def __init__(self, csd=None, cfg=None):
         super().__init__()
-        self.csd, self.cfg, self.calls = csd, cfg, 0
+        self.csd, self.cfg, self.calls, self.scales_seen = csd, cfg, 0, []
 
     def forward(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=1.0, guess_mode=False,
                 added_cond_kwargs=None, return_dict=True):
         from oracle import controlnet as ocn
-        assert not guess_mode and return_dict is False
+        assert return_dict is False
         self.calls += 1
+        self.scales_seen.append(float(conditioning_scale))
         return ocn.controlnet_forward(self.csd, self.cfg, sample, float(timestep), encoder_hidden_states, controlnet_cond, conditioning_scale,
-                                      added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"])
+                                      added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"], guess_mode=guess_mode)
 
 
 class StubMultiControlNetModel(nn.Module):
-    pass
+    """diffusers 0.25.0 ``MultiControlNetModel`` (third-party, recalled): ``.nets`` and a forward that calls every net with ITS image and ITS scale and
+    sums the residuals in list order.  The reference wraps a list / tuple of ControlNets in it (lora_pipeline.py:175-176) and tests ``isinstance`` of it
+    at :275-286, :366-383, :428."""
+    dtype = torch.float32          # ModelMixin.dtype (read at lora_pipeline.py:377)
+
+    def __init__(self, controlnets):
+        super().__init__()
+        self.nets = nn.ModuleList(controlnets)
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, controlnet_cond=None, conditioning_scale=None, guess_mode=False,
+                added_cond_kwargs=None, return_dict=True):
+        down = mid = None
+        for i, (image, scale, net) in enumerate(zip(controlnet_cond, conditioning_scale, self.nets)):
+            d, m = net(sample, timestep, encoder_hidden_states=encoder_hidden_states, controlnet_cond=image, conditioning_scale=scale,
+                       guess_mode=guess_mode, added_cond_kwargs=added_cond_kwargs, return_dict=return_dict)
+            if i == 0:
+                down, mid = d, m
+            else:
+                down = [a + b for a, b in zip(down, d)]
+                mid = mid + m
+        return down, mid
 
 
 def install_stubs():
@@ -395,6 +417,12 @@ CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, lat
     ("ddim_all_masks_none", "ddim", 18, 7.5, "all_none", False, (16, 16), "lora"),       # no concept pass runs: stage 2 == stage 1 (nothing is pasted, :581)
     # lora_pipeline.py:519-566 with `image` given: a ControlNet on the four main rows, none on the concept rows
     ("ddim_controlnet", "ddim", 18, 7.5, "overlap", False, (16, 16), "lora_cn"),
+    # round 6 — the ControlNet kwargs the engine used to refuse (CN_VARIANTS below): control_guidance_start / _end -> controlnet_keep (:275-286, :421-428,
+    # :511-517), guess_mode (:497-503, :531-535: the nets see the conditional rows only, zeros for the unconditional ones) and a LIST of ControlNets
+    # (MultiControlNetModel, :175-176, :366-383: one image, scale and guidance window per net, residuals summed)
+    ("ddim_controlnet_window", "ddim", 18, 7.5, "overlap", False, (16, 16), "lora_cn_window"),
+    ("ddim_controlnet_guess", "ddim", 18, 7.5, "overlap", False, (16, 16), "lora_cn_guess"),
+    ("euler_controlnet_multi", "euler", 18, 7.5, "none_mid", False, (16, 16), "lora_cn_multi"),
     # instantid_pipeline.py:540-707: IdentityNet (key-point image + face tokens) and the IP-Adapter branch on the concept rows, guidance 3
     # (inference_instantid.py:78); `iid_t2i`: + a second ControlNet (self.controlnet2, t2i_image) on the main rows (:574-592)
     ("euler_instantid", "euler", 18, 3.0, "overlap", False, (16, 16), "iid"),
@@ -402,6 +430,9 @@ CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, lat
 ]
 LORA_RANK, LORA_SEED0, LORA_SCALE = 8, 100, 0.8
 CN_SCALE, IDN_SCALE, T2I_SCALE, IP_SCALE, IP_TOKENS, FACE_DIM = 0.7, 0.8, 0.6, 0.8, 16, 512
+CN_VARIANTS = {"lora_cn": {}, "lora_cn_window": dict(control_guidance_start=0.2, control_guidance_end=0.7), "lora_cn_guess": dict(guess_mode=True),
+               # two nets: the second one's own image, scale and window; both act in steps 6..9 of 18
+               "lora_cn_multi": dict(control_guidance_start=[0.0, 0.3], control_guidance_end=[0.6, 1.0])}
 RESAMPLER = dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=IP_TOKENS, embedding_dim=FACE_DIM)      # instantid_single_pieline.py:163-174
 
 
@@ -473,7 +504,13 @@ def run_reference(c):
     vae.dtype = torch.float32
     vae.post_quant_conv = nn.Conv2d(4, 4, 1)
     cn = StubControlNetModel(c.get("csd"), c["cfg"])
-    image = c["pose"] if c["flow"] == "lora_cn" else None
+    image = c["pose"] if c["flow"].startswith("lora_cn") else None
+    cn_kw = dict(CN_VARIANTS.get(c["flow"], {}))
+    cn_scale = CN_SCALE
+    nets = [cn]
+    if c["flow"] == "lora_cn_multi":             # the reference's constructor wraps the list in MultiControlNetModel (lora_pipeline.py:175-176)
+        nets = [cn, StubControlNetModel(c["csd2"], c["cfg"])]
+        cn, image, cn_scale = nets, [c["pose"], c["pose2"]], [CN_SCALE, T2I_SCALE]
     pipe = LoraMultiConceptPipeline(vae=vae, text_encoder=None, text_encoder_2=None, tokenizer=None, tokenizer_2=None, unet=main_unet,
                                     controlnet=cn, scheduler=SchedulerAdapter(c["sched"], c["steps"]))
     pipe.embed_table = c["table"]
@@ -492,7 +529,7 @@ def run_reference(c):
             return r
         pipe.scheduler.step = step
         res = pipe(prompt=[[P, P], [REGION[k] for k in range(c["K"])]], negative_prompt=[NEG, NEG], image=image, height=c["H"], width=c["W"],
-                   controlnet_conditioning_scale=CN_SCALE,
+                   controlnet_conditioning_scale=cn_scale, **cn_kw,
                    num_inference_steps=c["steps"], guidance_scale=c["gs"], latents=c["lat0"].clone(), cross_attention_kwargs={"scale": LORA_SCALE},
                    controller=controller, concept_models=concept, stage=stage, region_masks=c["masks"], lora_list=[f"c{k}" for k in range(c["K"])],
                    styleL=c["style"], output_type="latent")
@@ -501,7 +538,9 @@ def run_reference(c):
         assert (controller.cur_step, controller.cur_att_layer) == (c["steps"], 0)
         out[f"stage{stage}"] = torch.stack(traj).numpy()
     out["set_adapters_calls"] = np.array(len(concept.calls))
-    out["controlnet_calls"] = np.array(cn.calls)
+    out["controlnet_calls"] = np.array(nets[0].calls)
+    if c["flow"] in ("lora_cn_window", "lora_cn_multi"):      # the conditioning_scale every call saw: scale * controlnet_keep[i], both stages back to back
+        out["controlnet_scales_seen"] = np.array([n_.scales_seen for n_ in nets])
     return out
 
 

@@ -221,14 +221,16 @@ def test_controller_source_vector_without_the_base_unconditional_row():
 
 
 def test_reference_parameters_that_are_not_implemented_are_refused_not_ignored():
-    """B3: a non-default value of a parameter the reference's __call__ acts on (guess_mode, control_guidance_start / _end -> controlnet_keep,
-    callbacks, prompt_2, ...) must raise — silently dropping it returns an image the reference would not have produced; names nobody knows raise
+    """B3: a non-default value of a parameter the reference's __call__ acts on and this engine does not implement (callbacks, prompt_2, clip_skip,
+    ...; round 6 implemented guess_mode, control_guidance_start / _end and a list of ControlNets — tests/test_pipeline_gpu.py) must raise — silently dropping it returns an image the reference would not have produced; names nobody knows raise
     too; what the shipped scripts pass and the reference itself never reads (inference_lora.py:241-245 `spatial_condition`) is accepted."""
     from omg_amd import _lib as L
     from omg_amd.pipeline import InstantidMultiConceptPipeline, LoraMultiConceptPipeline, refuse_unimplemented
 
     lp, ip = object.__new__(LoraMultiConceptPipeline), object.__new__(InstantidMultiConceptPipeline)
-    for bad in (dict(guess_mode=True), dict(control_guidance_start=0.2), dict(control_guidance_end=[0.8]), dict(callback_on_step_end=print),
+    with pytest.raises(L.OmgHipError):      # the reference's own InstantID loop fails on guess_mode (instantid_pipeline.py:638-657): refused with that explanation
+        ip(prompt_embeds=torch.zeros(2, 77, 8), guess_mode=True)
+    for bad in (dict(callback_on_step_end=print),
                 dict(callback=print, callback_steps=1), dict(prompt_2="x"), dict(num_images_per_prompt=2), dict(clip_skip=2),
                 dict(negative_original_size=(512, 512)), dict(guidance_rescale=0.7), dict(denoising_end=0.8), dict(no_such_argument=1)):
         with pytest.raises(L.OmgHipError):
@@ -237,5 +239,34 @@ def test_reference_parameters_that_are_not_implemented_are_refused_not_ignored()
             with pytest.raises(L.OmgHipError):
                 ip(prompt_embeds=torch.zeros(2, 77, 8), **bad)
     # defaults in any of the reference's spellings, and the names its **kwargs swallows, pass the gate
-    refuse_unimplemented(dict(guess_mode=False, control_guidance_start=[0.0], control_guidance_end=1.0, callback=None, negative_crops_coords_top_left=[0, 0]),
+    refuse_unimplemented(dict(callback=None, negative_crops_coords_top_left=[0, 0], clip_skip=None),
                          dict(spatial_condition=None, indices_to_alter=None, callback_on_step_end_tensor_inputs=["latents"]), "test")
+
+
+def test_controlnet_keep_is_the_reference_s_schedule():
+    """lora_pipeline.py:275-286, :421-428, :511-517: the per-step factor on every ControlNet's conditioning scale.  Pinned by what the reference's own
+    loop handed its ControlNets in the build container (tests/golden/make_golden_loop.py records every `conditioning_scale` it was called with)."""
+    import os
+    import sys
+    import numpy as np
+    from omg_amd.pipeline import controlnet_keep
+    gold_dir = os.path.join(os.path.dirname(__file__), "golden")
+    sys.path.insert(0, gold_dir)
+    import make_golden_loop as mk
+    gold = np.load(os.path.join(gold_dir, "loop_golden.npz"))
+    for case in mk.CASES:
+        name, steps, flow = case[0], case[2], case[7]
+        if f"{name}/controlnet_scales_seen" not in gold.files:
+            continue
+        seen = gold[f"{name}/controlnet_scales_seen"]                     # (nets, 2 stages x steps)
+        kw = mk.CN_VARIANTS[flow]
+        keep = controlnet_keep(steps, kw.get("control_guidance_start", 0.0), kw.get("control_guidance_end", 1.0), seen.shape[0])
+        sc = [mk.CN_SCALE, mk.T2I_SCALE][: seen.shape[0]]
+        want = np.array([[sc[k] * keep[i][k] for i in range(steps)] * 2 for k in range(seen.shape[0])])
+        assert np.array_equal(seen, want), name
+    # scalars broadcast to every net; a scalar start beside a list of ends (and the other way round) as :275-279
+    assert controlnet_keep(4, 0.0, 1.0, 3) == [[1.0] * 3] * 4
+    assert controlnet_keep(4, 0.5, [1.0, 0.75]) == [[0.0, 0.0], [0.0, 0.0], [1.0, 1.0], [1.0, 0.0]]
+    assert controlnet_keep(4, [0.0, 0.25], 0.5) == [[1.0, 0.0], [1.0, 1.0], [0.0, 0.0], [0.0, 0.0]]
+    with pytest.raises(ValueError):
+        controlnet_keep(4, [0.0, 0.1], [1.0])

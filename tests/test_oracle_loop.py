@@ -48,12 +48,23 @@ def oracle_run(c, stage, num_att_layers):
     main_lora = fn["style"] if c["style"] else None              # inference_lora.py:162-164 + the main call's scale 0.8 (:546-566)
 
     flow = c["flow"]
+    cn_kw = mk.CN_VARIANTS.get(flow, {})
+    if flow.startswith("lora_cn"):
+        # lora_pipeline.py:519-536: the ControlNet sees the four main rows with the main context; its residuals feed the main UNet only.  Round 6: + the guidance
+        # window (controlnet_keep, :421-428, :511-517), guess_mode (:497-503, :531-535) and a list of nets (MultiControlNetModel) — oracle/pipeline.py
+        multi = flow == "lora_cn_multi"
+        csds = [c["csd"], c["csd2"]] if multi else [c["csd"]]
+        images = [c["pose"], c["pose2"]] if multi else [c["pose"]]
+        scales = [mk.CN_SCALE, mk.T2I_SCALE] if multi else [mk.CN_SCALE]
+        keep = opipe.controlnet_keep(S, cn_kw.get("control_guidance_start", 0.0), cn_kw.get("control_guidance_end", 1.0), len(csds))
+        nets = [lambda x, i, ctx, img, sc, te, tid_, gm, csd=csd: ocn.controlnet_forward(csd, cfg, x, float(osch.timesteps[i]), ctx, img, sc, te, tid_, guess_mode=gm)
+                for csd in csds]
 
     def main(x, i):
         t = float(osch.timesteps[i])
         down = mid = None
-        if flow == "lora_cn":        # lora_pipeline.py:519-536: the ControlNet sees the four main rows with the main context; its residuals feed the main UNet only
-            down, mid = ocn.controlnet_forward(c["csd"], cfg, x, t, ctx4, c["pose"].repeat(4, 1, 1, 1), mk.CN_SCALE, te4, tid.repeat(4, 1))
+        if flow.startswith("lora_cn"):
+            down, mid = opipe.main_controlnet_residuals(nets, x, i, ctx4, te4, tid.repeat(4, 1), images, scales, keep[i], cn_kw.get("guess_mode", False))
         if flow == "iid_t2i":        # instantid_pipeline.py:574-592: self.controlnet2 on the main rows with t2i_image
             down, mid = ocn.controlnet_forward(c["csd2"], cfg, x, t, ctx4, c["pose2"].repeat(4, 1, 1, 1), mk.T2I_SCALE, te4, tid.repeat(4, 1))
         return ou.unet_forward(sd, cfg, x, t, ctx4, te4, tid.repeat(4, 1), attn_fn=attn, lora=main_lora,
@@ -121,4 +132,11 @@ def test_oracle_loop_matches_the_reference_pipeline_run_here(gold, case):
         assert int(gold[f"{c['name']}/controlnet2_calls"]) == (2 * c["steps"] if c["flow"] == "iid_t2i" else 0)
     else:
         assert int(gold[f"{c['name']}/set_adapters_calls"]) == 2 * c["K"] + n_masked * fused
-        assert int(gold[f"{c['name']}/controlnet_calls"]) == (2 * c["steps"] if c["flow"] == "lora_cn" else 0)
+        assert int(gold[f"{c['name']}/controlnet_calls"]) == (2 * c["steps"] if c["flow"].startswith("lora_cn") else 0)      # called every step, also at keep = 0
+        if f"{c['name']}/controlnet_scales_seen" in gold.files:      # what the reference handed every net: scale_k * controlnet_keep[i][k], stage 1 then stage 2
+            seen = gold[f"{c['name']}/controlnet_scales_seen"]
+            kw = mk.CN_VARIANTS[c["flow"]]
+            keep = opipe.controlnet_keep(c["steps"], kw.get("control_guidance_start", 0.0), kw.get("control_guidance_end", 1.0), seen.shape[0])
+            sc = [mk.CN_SCALE, mk.T2I_SCALE][: seen.shape[0]]
+            want = np.array([[sc[k] * keep[i][k] for i in range(c["steps"])] * 2 for k in range(seen.shape[0])])
+            assert np.array_equal(seen, want) and (want == 0).any() and (want != 0).any()
