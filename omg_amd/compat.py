@@ -518,9 +518,10 @@ def install(stub_missing: bool = True) -> List[str]:
     module("src.prompt_attention.p2p_attention", AttentionReplace=AttentionReplace)
     # a REAL diffusers (none in this image; a user's environment may have one) is set aside whole and restored by uninstall(): the aliases never
     # patch it (package("diffusers") imported the real package and overwrote four of its attributes for good)
-    global _SAVED_DIFFUSERS
-    _SAVED_DIFFUSERS = {n: sys.modules.pop(n) for n in [n for n in sys.modules if n == "diffusers" or n.startswith("diffusers.")]
-                        if not getattr(sys.modules[n], "__dict__", {}).get("__omg_amd_alias__", False)}
+    # MERGED, not overwritten: a second install() without an uninstall() in between finds only the aliases, and assigning that empty result dropped the
+    # real package the first call had set aside for good
+    _SAVED_DIFFUSERS.update({n: sys.modules.pop(n) for n in [n for n in sys.modules if n == "diffusers" or n.startswith("diffusers.")]
+                             if not getattr(sys.modules[n], "__dict__", {}).get("__omg_amd_alias__", False)})
     d = types.ModuleType("diffusers")
     d.__path__ = []
     d.__omg_amd_alias__ = True

@@ -754,6 +754,7 @@ AttnP make_params(const omg_attn_args* a) {
   return p;
 }
 
+constexpr int ATTN_V7_DEFAULT_DEN = 0;      // the product's denominator form (attn_v7.h)
 int g_attn_variant = 0;      // 0 = heuristic (above 128 keys: v7 when V is given row-major, else v3; v6 up to 128; v2 when O is not 16-byte aligned), 2 / 3 / 6 force one; tools / A-B tests only
 
 }  // namespace
@@ -778,13 +779,16 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // row-major V (omg_attn_args.V): the self-attention kernel reads it in place — no omg_transpose_v pass.  Up to 128 keys the resident-K/V kernel
   // (v6) and v2 want the V^T image: a caller that passes only V there gets an error, not a silent fallback.
-  if (a->V != nullptr && (g_attn_variant == 0 || g_attn_variant == 7) && (a->Nkv > 128 || a->Vt == nullptr)) {
+  if (a->V != nullptr && (g_attn_variant == 0 || (g_attn_variant >= 7 && g_attn_variant <= 9)) && (a->Nkv > 128 || a->Vt == nullptr)) {
     OMG_REQUIRE(a->ldv % 8 == 0 && a->v_bstride % 8 == 0, "omg_attn_fwd: V strides must be multiples of 8 elements");
     OMG_REQUIRE(a->Nkv > 128, "omg_attn_fwd: row-major V needs more than 128 keys (pass Vt from omg_transpose_v below that)");
     dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);
     const int xcd_order = g_attn_natural_order ? 0 : 1;
-    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel7<f16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order);
-    else OMG_LAUNCH(attn_fwd_kernel7<bf16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order);
+    const int den = g_attn_variant == 0 ? ATTN_V7_DEFAULT_DEN : g_attn_variant - 7;      // tools: 7 / 8 / 9 force the denominator form 0 / 1 / 2 (attn_v7.h)
+#define OMG_V7(T_, D_) OMG_LAUNCH((attn_fwd_kernel7<T_, D_>), grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order)
+    if (a->dtype == OMG_F16) { if (den == 0) OMG_V7(f16, 0); else if (den == 1) OMG_V7(f16, 1); else OMG_V7(f16, 2); }
+    else { if (den == 0) OMG_V7(bf16, 0); else if (den == 1) OMG_V7(bf16, 1); else OMG_V7(bf16, 2); }
+#undef OMG_V7
     return omg_check_launch("attn_fwd_v7");
   }
   OMG_REQUIRE(a->Vt != nullptr, "omg_attn_fwd: this variant needs Vt");

@@ -22,11 +22,13 @@ template <> struct Vec<f16> {
   using v8 = f16x8; using v4 = f16x4;
   static constexpr bool is_f16 = true;
   static OMG_DEV f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static OMG_DEV f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct Vec<bf16> {
   using v8 = bf16x8; using v4 = bf16x4;
   static constexpr bool is_f16 = false;
   static OMG_DEV f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static OMG_DEV f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
 template <typename T> OMG_DEV float to_f32(T x) { return (float)x; }

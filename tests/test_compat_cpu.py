@@ -191,3 +191,27 @@ def test_run_module_resolves_the_checkouts_own_src_packages_from_a_foreign_cwd(t
     assert got == {"answer": 42, "pipe": "omg_amd.compat", "alias": True}
     assert sys.modules["diffusers"] is real and sys.modules["diffusers.models"] is real_sub and not hasattr(real, "ControlNetModel")
     assert not any(getattr(m, "__dict__", {}).get("__omg_amd_alias__", False) for m in list(sys.modules.values()) if m is not None)
+
+
+def test_install_twice_then_uninstall_restores_a_real_diffusers(monkeypatch):
+    """the second install() of a session (no uninstall() in between) sees only the alias modules; the real `diffusers` the first call set
+    aside must survive it and come back with uninstall()."""
+    import sys
+    import types
+    from omg_amd import compat
+    real = types.ModuleType("diffusers"); real.MARK = "real"
+    real_sub = types.ModuleType("diffusers.utils"); real_sub.MARK = "real.utils"
+    monkeypatch.setitem(sys.modules, "diffusers", real)
+    monkeypatch.setitem(sys.modules, "diffusers.utils", real_sub)
+    saved_src = {n: m for n, m in sys.modules.items() if n == "src" or n.startswith("src.")}
+    for n in saved_src:
+        monkeypatch.delitem(sys.modules, n)
+    try:
+        compat.install()
+        assert getattr(sys.modules["diffusers"], "__omg_amd_alias__", False)
+        compat.install()
+        assert getattr(sys.modules["diffusers"], "__omg_amd_alias__", False)
+    finally:
+        compat.uninstall()
+    assert sys.modules["diffusers"] is real and sys.modules["diffusers.utils"] is real_sub
+    assert not any(getattr(m, "__dict__", {}).get("__omg_amd_alias__", False) for m in list(sys.modules.values()) if m is not None)

@@ -91,6 +91,30 @@ def test_geglu_gate_function_is_gelu_to_one_half_precision_ulp(dev):
     assert bool((err <= tol).all()), f"worst: {(err / tol).max().item():.2f} x the bound at gate {gate.flatten()[(err / tol).argmax()].item():.3f}"
 
 
+def test_geglu_gate_of_non_finite_values(dev):
+    """what csrc/gelu.h does with inf / NaN gates, pinned.  Gate = bias (zero weights): +inf -> +inf, -inf -> 0, a NaN with a clear sign bit
+    -> NaN; a NaN with the sign bit set is documented as NOT propagated (it may come out 0) — the test accepts either and says which."""
+    dtype = torch.float16
+    M, K, Cn = 256, 64, 256
+    a = rnd(M, K, dtype=dtype, dev=dev)
+    gates = torch.zeros(Cn, dtype=dtype)
+    gates[0], gates[1], gates[2], gates[4], gates[5] = float("inf"), float("-inf"), 3.0, 65504.0, -65504.0
+    gates_bits = gates.view(torch.int16)
+    gates_bits[6], gates_bits[7] = 0x7E00, -512            # +qNaN (0x7E00), -qNaN (0xFE00)
+    w = torch.zeros(2 * Cn, K, dtype=dtype, device=dev)
+    b = torch.cat([torch.ones(Cn, dtype=dtype), gates]).to(dev)
+    perm = ops.geglu_row_perm(2 * Cn).to(dev)
+    out = ops.gemm(a, w[perm].contiguous(), bias=b[perm].contiguous(), act=L.ACT_GEGLU).float().cpu()
+    assert torch.isinf(out[:, 0]).all() and (out[:, 0] > 0).all()
+    assert (out[:, 1] == 0).all() and (out[:, 2] - 2.9959).abs().max() < 2e-3
+    assert (out[:, 4] == 65504.0).all() and (out[:, 5] == 0).all()
+    assert torch.isnan(out[:, 6]).all()
+    neg_nan = out[:, 7]
+    assert bool(torch.isnan(neg_nan).all()) or bool((neg_nan == 0).all())
+    print("gate = NaN with the sign bit set comes out", "NaN" if torch.isnan(neg_nan).all() else "0 (documented in csrc/gelu.h)")
+    assert torch.isfinite(out[:, 8:]).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_group_bias_and_strided(dev, dtype):
     B, rows, N, K = 3, 100, 320, 192
@@ -271,6 +295,44 @@ def test_row_major_v_attention_is_bitwise_the_transposed_v_kernel(dev, dtype, B,
     for x, y in zip(res["v3"], res["v7"]):
         assert torch.equal(x, y), (x.float() - y.float()).abs().max().item()
     close(res["v7"][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 3, 300, 256), (2, 2, 1024, 1000), (1, 2, 512, 4096), (3, 1, 100, 130), (2, 4, 1024, 1024)])
+def test_attention_denominator_forms_agree(dev, dtype, B, heads, Nq, Nkv):
+    """attn_fwd_kernel7<T, DEN> (csrc/attn_v7.h, round 6): the row sums of P by a 32-row ones MFMA (0, round 3's form), by the 16 x 16 x 32 MFMA into a
+    persistent 4-register accumulator (1) or by fp32 adds of the exponentials (2).  Every form against the fp32 reference, and the forms against each
+    other to two 16-bit ulps: 0 and 1 sum the ROUNDED probabilities in a different order, 2 sums the unrounded ones.  Rows that force the rescale
+    branch in a LATE tile (form 1 folds its matrix-pipe partial sum into the lane-local one there) are planted."""
+    from omg_amd import _lib as L
+    Cc = heads * 64
+    qkv = rnd(B, max(Nq, Nkv), 3 * Cc, dtype=dtype, dev=dev, scale=1.2)
+    q, k, v = qkv[:, :Nq, :Cc], qkv[:, :Nkv, Cc:2 * Cc], qkv[:, :Nkv, 2 * Cc:]
+    q[0, 0] = 0                                   # all logits equal
+    q[0, 1] = k[0, 5] * 4                         # dominant logit in the first tile
+    q[0, 2] = k[0, Nkv - 3] * 4                   # ... in the last (possibly ragged) tile: a rescale with sums pending
+    q[0, 40] = k[0, Nkv // 2 + 1] * 3             # ... in the middle, another query block of the same wave
+    vr = ops.value_operand(v, heads)
+    assert isinstance(vr, ops.RowMajorV)
+    src = torch.tensor([max(0, b - 1) for b in range(B)], dtype=torch.int32, device=dev)
+    res = {}
+    try:
+        for var in (7, 8, 9):
+            L.lib().omg_debug_set_attn_variant(var)
+            a = ops.attention(q, k, vr, heads, 0.125)
+            b_ = ops.attention(q, k, vr, heads, 0.125, qk_src=src)
+            c = a.clone()
+            ops.attention(q, k, vr, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
+            res[var] = (a, b_, c)
+    finally:
+        L.lib().omg_debug_set_attn_variant(0)
+    ref = attn_ref(q, k, v, heads, 0.125)
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    for var in (7, 8, 9):
+        close(res[var][0], ref, dtype, scale=2.0)
+        for x, y in zip(res[7], res[var]):
+            d = (x.float() - y.float()).abs()
+            assert bool((d <= 2 * ulp * x.float().abs() + 1e-6).all()), (var, d.max().item())
 
 
 def test_row_major_v_is_refused_where_no_kernel_reads_it(dev):

@@ -42,7 +42,7 @@ for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20,
     fl = 4.0 * B * heads * Nq * Nkv * 64
     res, outs = [], []
     for var in VARS:
-        operand = vr if var in (0, 7) else vt
+        operand = vr if var in (0, 7, 8, 9) else vt      # 7 / 8 / 9: v7 with the denominator form 0 / 1 / 2 (csrc/attn_v7.h)
         lib.omg_debug_set_attn_variant(var)
         ms = timeit(lambda: ops.attention(q, k, operand, heads, 0.125, out=out))
         res.append(fl / ms / 1e9)
