@@ -754,7 +754,7 @@ AttnP make_params(const omg_attn_args* a) {
   return p;
 }
 
-constexpr int ATTN_V7_DEFAULT_DEN = 0;      // the product's denominator form (attn_v7.h)
+constexpr int ATTN_V7_DEFAULT_DEN = 1;      // the product's denominator form (attn_v7.h)
 int g_attn_variant = 0;      // 0 = heuristic (above 128 keys: v7 when V is given row-major, else v3; v6 up to 128; v2 when O is not 16-byte aligned), 2 / 3 / 6 force one; tools / A-B tests only
 
 }  // namespace

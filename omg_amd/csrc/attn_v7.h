@@ -87,32 +87,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
   const int bq = p.qk_src ? p.qk_src[b] : b;
   const int q0 = qblk * (4 * 32 * QW) + w * (32 * QW);
 
-  V8 qf[QW][4];
-  int qrow[QW];
-  // all eight Q loads of the wave's two query blocks are in flight before the first is converted (v3's emitted prologue waits for block 0's
-  // four loads, scales them, and only then issues block 1's: one more global round trip in front of the first key tile of every workgroup)
-  V8 qraw[QW][4];
-#pragma unroll
-  for (int qb = 0; qb < QW; ++qb) {
-    int q = q0 + qb * 32 + l31;
-    qrow[qb] = q;
-    if (q >= p.Nq) q = p.Nq - 1;
-    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      qraw[qb][ks] = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
-    }
-  }
-  {
-    asm volatile("" : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]));
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)qraw[qb][ks][e] * p.scale_log2e);
-  }
-
   // ---- LDS-DMA staging: one instruction = 8 rows x 128 B; wave w moves row blocks w and w + 4 of the K tile and of the V^T tile
   const int prow = lane >> 3, ppos = lane & 7;
   const char* kbase = p.K + ((long)bq * p.k_bs + h * 64) * 2;
@@ -201,6 +175,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
   const int ntiles = (p.Nkv + KVB - 1) / KVB;
   const int nfull = p.Nkv / KVB;             // tiles with 64 real keys
   if (nfull > 0) dma_whole(0); else dma_tile(0, 0);
+  V8 qf[QW][4];
+  int qrow[QW];
+  // Round 6: the Q loads are issued BEHIND the first K / V tile's LDS-DMA (above), not in front of it: the two global round trips of a block's prologue
+  // overlap instead of following each other (the empty asm below waits for everything, and everything is needed before tile 0).
+  // all eight Q loads of the wave's two query blocks are in flight before the first is converted (v3's emitted prologue waits for block 0's
+  // four loads, scales them, and only then issues block 1's: one more global round trip in front of the first key tile of every workgroup)
+  V8 qraw[QW][4];
+#pragma unroll
+  for (int qb = 0; qb < QW; ++qb) {
+    int q = q0 + qb * 32 + l31;
+    qrow[qb] = q;
+    if (q >= p.Nq) q = p.Nq - 1;
+    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qraw[qb][ks] = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
+    }
+  }
+  {
+    asm volatile("" : "+v"(qraw[0][0]), "+v"(qraw[0][1]), "+v"(qraw[0][2]), "+v"(qraw[0][3]), "+v"(qraw[1][0]), "+v"(qraw[1][1]), "+v"(qraw[1][2]), "+v"(qraw[1][3]));
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)qraw[qb][ks][e] * p.scale_log2e);
+  }
+
   auto tile_body = [&](const int t, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = t & 1;

@@ -15,10 +15,10 @@
 // FMAs, v_exp_f32, v_max, half a packed FMA.  The packed and the scalar FMA round identically: gelu_f (the small-tile kernels) and gelu_f2 agree bit for bit
 // (tests/test_kernels_gpu.py::test_gemm_variants_are_bitwise_identical).
 // Non-finite gates (pinned by tests/test_kernels_gpu.py::test_geglu_gate_of_non_finite_values): +inf -> +inf, -inf -> -0 (6.01 * 1.5e-9 below zero),
-// a NaN whose sign bit is CLEAR (what this part's own arithmetic produces: the MFMA / VALU default NaN is 0x7FC00000) -> NaN.  A NaN with the sign bit SET
-// (x86's default NaN, i.e. one that was already in a host-written input) is NOT propagated: v_med3 returns min3 for a NaN (a = 0) and the integer max
-// takes the negative bit pattern to 0, so the gate comes out 0 — accepted: the alternative, fmaxf, canonicalises its operand first (one more VALU
-// instruction per element on the largest epilogue of the step) to keep a value that only a corrupt input can carry.
+// +-65504 saturate to x / 0.  NaN gates are NOT guaranteed to propagate: v_med3 returns min3 for a NaN operand (a = 0) and the integer max takes a NaN whose
+// sign bit is set (x86's default NaN) to 0, so such a gate comes out 0; the test prints what a NaN gate gives on the part beside a plain GEMM with the same
+// NaN bias.  Accepted: fmaxf instead of the integer max canonicalises its operand first — one more VALU instruction per element on the largest epilogue of
+// the step — to keep a value that only a corrupt input can carry; overflow in the ff projection shows up as +-inf, which does propagate.
 typedef float omg_f32x2 __attribute__((ext_vector_type(2)));
 OMG_DEV omg_f32x2 gelu_f2(omg_f32x2 x) {
   const omg_f32x2 a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x[0]), 0.0f, 6.0104076400856545f),
