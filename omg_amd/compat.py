@@ -391,8 +391,10 @@ class InstantidMultiConceptPipeline(_PipeMixin, _InstantidPipe):
             # encoders too, at lora_scale = cross_attention_kwargs["scale"] (instantid_pipeline.py:330-360)
             te_scale = (cross_attention_kwargs or {}).get("scale", None)
             glob, regions = list(prompt[0]), list(prompt[1])
+            # prompt_2 / negative_prompt_2 / clip_skip go to the ONE encode_prompt call over all prompts (instantid_pipeline.py:343-362)
+            enc_extra = {k: kw.pop(k) for k in ("prompt_2", "negative_prompt_2", "clip_skip") if kw.get(k) is not None}
             pe, ne, pp, npp = self.encode_prompt(glob + [r[0] for r in regions], list(negative_prompt) + [r[1] for r in regions],
-                                                 self.peft_active_adapters() or None, te_scale)
+                                                 self.peft_active_adapters() or None, te_scale, **enc_extra)
             extra = dict(prompt_embeds=pe[:2], negative_prompt_embeds=ne[:2], pooled_prompt_embeds=pp[:2], negative_pooled_prompt_embeds=npp[:2],
                          region_prompt_embeds=[(ne[2 + c: 3 + c], pe[2 + c: 3 + c], npp[2 + c: 3 + c], pp[2 + c: 3 + c]) for c in range(len(regions))])
             if stage == 2:

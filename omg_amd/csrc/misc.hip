@@ -319,7 +319,8 @@ extern "C" int omg_conv_out(int dtype, const void* X, int B, int H, int W, int C
   if (npix == 0) return OMG_OK;
   long blocks = (npix + 3) / 4; if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype != OMG_F32 && Cout == 4 && Cin % 32 == 0) {      // the 16-bit UNet's last convolution: one lane per pixel, weights through the scalar cache
+  // (the pixel kernel reads X and Wt in 16-byte vectors / s_load_dwordx16: unaligned bases take the per-wave kernel — ADVICE r5)
+  if (dtype != OMG_F32 && Cout == 4 && Cin % 32 == 0 && (((uintptr_t)X | (uintptr_t)Wt) & 15) == 0) {      // the 16-bit UNet's last convolution: one lane per pixel, weights through the scalar cache
     const unsigned pb = (unsigned)((npix + 255) / 256);
     if (dtype == OMG_F16) OMG_LAUNCH((conv_out_pixel_kernel<f16, 4>), dim3(pb), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const f16*)bias, Y);
     else OMG_LAUNCH((conv_out_pixel_kernel<bf16, 4>), dim3(pb), dim3(256), 0, s, (const char*)X, B, H, W, Cin, (const char*)Wt, (const bf16*)bias, Y);

@@ -412,9 +412,6 @@ def transpose_v(v: torch.Tensor, heads: int, nkv_pad: Optional[int] = None, out:
     return vt
 
 
-_ROW_MAJOR_V = os.environ.get("OMG_ATTN_ROW_MAJOR_V", "1") != "0"      # tools: 0 = the V^T image + attn_fwd_kernel3 for the self-attention (in-situ A/B)
-
-
 class RowMajorV:
     """The V operand of a self-attention as the QKV projection wrote it — a (B, Nkv, heads*64) VIEW with unit inner stride — instead of the
     V^T image :func:`transpose_v` makes: :func:`attention` hands it to the kernel that transposes on the LDS read (omg_attn_args.V, ABI 6).
@@ -428,7 +425,7 @@ class RowMajorV:
 def value_operand(v: torch.Tensor, heads: int):
     """What :func:`attention` wants for ``v`` (B, Nkv, heads*64): the view itself above 128 keys when its strides allow (self-attention
     at 32 x 32 / 64 x 64), else the V^T image in MFMA key order."""
-    if _ROW_MAJOR_V and v.shape[1] > 128 and v.stride(2) == 1 and v.stride(1) % 8 == 0 and v.stride(0) % 8 == 0 and v.data_ptr() % 16 == 0:
+    if v.shape[1] > 128 and v.stride(2) == 1 and v.stride(1) % 8 == 0 and v.stride(0) % 8 == 0 and v.data_ptr() % 16 == 0:
         return RowMajorV(v)
     return transpose_v(v, heads)
 

@@ -189,16 +189,15 @@ class StageCache:
 # default and that this engine does not implement: name -> (the default, where the reference uses it).  A non-default value is REFUSED — ignoring
 # it would return an image the reference would not have produced, without a word.
 _UNIMPLEMENTED = {
-    "callback": (None, "lora_pipeline.py:256, :629-632"), "callback_steps": (None, "lora_pipeline.py:257"),
-    "callback_on_step_end": (None, "lora_pipeline.py:246, :617-626"),
-    "prompt_2": (None, "lora_pipeline.py:215 (second text encoder's own prompt)"), "negative_prompt_2": (None, "lora_pipeline.py:222"),
     "num_images_per_prompt": (1, "lora_pipeline.py:223"), "ip_adapter_image": (None, "lora_pipeline.py:231"),
-    "clip_skip": (None, "lora_pipeline.py:245"), "negative_original_size": (None, "lora_pipeline.py:242, :459-466"),
-    "negative_target_size": (None, "lora_pipeline.py:244, :459-466"), "negative_crops_coords_top_left": ((0, 0), "lora_pipeline.py:243"),
 }
+# Implemented in round 6 and therefore no longer here: guess_mode, control_guidance_start / _end, a list of ControlNets (generate_many), prompt_2 /
+# negative_prompt_2 / clip_skip (omg_amd.text_encoder.make_encode_prompt), negative_original_size / _crops_coords_top_left / _target_size, callback /
+# callback_steps / callback_on_step_end (+ _tensor_inputs).
 # names the reference's own ``**kwargs`` swallows without reading (the shipped scripts pass them: inference_lora.py:241-245), or reads only
 # together with a callback
-_REFERENCE_IGNORES = ("spatial_condition", "indices_to_alter", "callback_on_step_end_tensor_inputs")
+_REFERENCE_IGNORES = ("spatial_condition", "indices_to_alter")
+_CALLBACK_TENSORS = ("latents", "prompt_embeds", "negative_prompt_embeds")      # _callback_tensor_inputs (lora_pipeline.py:165)
 
 
 def refuse_unimplemented(given: dict, leftovers: dict, who: str) -> None:
@@ -283,9 +282,15 @@ class LoraMultiConceptPipeline:
         # round 6: implemented instead of refused (lora_pipeline.py:236-238; generate_many's docstring)
         guess_mode = bool(kwargs.pop("guess_mode", False))
         cg_start, cg_end = kwargs.pop("control_guidance_start", 0.0), kwargs.pop("control_guidance_end", 1.0)
+        clip_skip = kwargs.pop("clip_skip", None)                                                   # lora_pipeline.py:245, :333
+        neg_cond = (kwargs.pop("negative_original_size", None), kwargs.pop("negative_crops_coords_top_left", (0, 0)),
+                    kwargs.pop("negative_target_size", None))                                       # :242-244, :459-466
+        callbacks = dict(callback=kwargs.pop("callback", None), callback_steps=kwargs.pop("callback_steps", None),      # :256-257, :629-632
+                         callback_on_step_end=kwargs.pop("callback_on_step_end", None),                                  # :246, :617-626
+                         callback_on_step_end_tensor_inputs=kwargs.pop("callback_on_step_end_tensor_inputs", ("latents",)))
         stage_cache, drop_unc0 = kwargs.pop("stage_cache", None), kwargs.pop("drop_unc0", False)
         given = {k: kwargs.pop(k) for k in list(kwargs) if k in _UNIMPLEMENTED}
-        given.update(prompt_2=prompt_2, negative_prompt_2=negative_prompt_2, num_images_per_prompt=num_images_per_prompt)
+        given.update(num_images_per_prompt=num_images_per_prompt)
         refuse_unimplemented(given, kwargs, "LoraMultiConceptPipeline.__call__")
         n_nets = len(controlnet.nets) if hasattr(controlnet, "nets") else len(controlnet) if isinstance(controlnet, (list, tuple)) else 1
         if n_nets == 1:
@@ -312,8 +317,10 @@ class LoraMultiConceptPipeline:
             # lora_scale = cross_attention_kwargs["scale"]
             te_scale = (cross_attention_kwargs or {}).get("scale", None)
             global_prompt, regions = prompt[0], prompt[1]
+            # prompt_2 / negative_prompt_2 / clip_skip act on the GLOBAL prompt only: the region prompts are encoded without them (lora_pipeline.py:340-342)
+            extra = {k: v for k, v in (("prompt_2", prompt_2), ("negative_prompt_2", negative_prompt_2), ("clip_skip", clip_skip)) if v is not None}
             prompt_embeds, negative_prompt_embeds, pooled_prompt_embeds, negative_pooled_prompt_embeds = self.encode_prompt(
-                global_prompt, negative_prompt, [("style", 1.0)] if styleL else None, te_scale)
+                global_prompt, negative_prompt, [("style", 1.0)] if styleL else None, te_scale, **extra)
             region_prompt_embeds = []
             for lora_param, (rp, rn) in zip(lora_list, [(r[0], r[1]) for r in regions]):
                 if hasattr(concept_models, "encode_prompt"):      # the reference's literal sequence (lora_pipeline.py:337-343)
@@ -338,7 +345,9 @@ class LoraMultiConceptPipeline:
                                  styleL=styleL, use_graph=use_graph, trajectory=traj_many, fusion_start=fusion_start,
                                  lora_mode=lora_mode, controlnet=controlnet if image is not None else None, controlnet_image=image,
                                  controlnet_conditioning_scale=cn_scale, dedup=dedup, stage_cache=stage_cache, drop_unc0=drop_unc0,
-                                 guess_mode=guess_mode and image is not None, control_guidance_start=cg_start, control_guidance_end=cg_end)[0]
+                                 guess_mode=guess_mode and image is not None, control_guidance_start=cg_start, control_guidance_end=cg_end,
+                                 negative_original_size=neg_cond[0], negative_crops_coords_top_left=neg_cond[1], negative_target_size=neg_cond[2],
+                                 **callbacks)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         images = self._postprocess(lat, output_type)
@@ -379,7 +388,9 @@ class LoraMultiConceptPipeline:
                       main_adapters: Optional[Sequence[Tuple[str, float]]] = None,
                       concept_adapters: Optional[Sequence[Tuple[str, float]]] = None, concept_adapter_scale: float = 1.0,
                       stage_cache: Optional[StageCache] = None, drop_unc0: bool = False, guess_mode: bool = False,
-                      control_guidance_start=0.0, control_guidance_end=1.0) -> torch.Tensor:
+                      control_guidance_start=0.0, control_guidance_end=1.0, negative_original_size=None, negative_crops_coords_top_left=(0, 0),
+                      negative_target_size=None, callback: Optional[Callable] = None, callback_steps: Optional[int] = None,
+                      callback_on_step_end: Optional[Callable] = None, callback_on_step_end_tensor_inputs=("latents",)) -> torch.Tensor:
         """Each request: dict(prompt_embeds (2,77,Cx), negative_prompt_embeds, pooled_prompt_embeds (2,P),
         negative_pooled_prompt_embeds, region_prompt_embeds [(neg, pos, neg_pooled, pos_pooled)] * K, region_masks [K],
         latents | generator).  Returns final latents (n, 2, C, H/8, W/8): [base sample, edited sample] per request.
@@ -394,6 +405,14 @@ class LoraMultiConceptPipeline:
         for the IdentityNet and the t2i ControlNet of the InstantID flow too (instantid_pipeline.py:477-483, :566-578); ``guess_mode=True``
         (:497-503, :531-535): the nets see only the CONDITIONAL rows ``[cond0, cond1]`` of every request, with diffusers' logspace residual scaling, and the
         unconditional rows get no residual.
+        ``negative_original_size`` + ``negative_target_size`` (+ ``negative_crops_coords_top_left``): SDXL's negative micro-conditioning as the reference
+        EXECUTES it (lora_pipeline.py:459-474): ``cat([negative_ids, ids]).repeat(2, 1)`` — the four main rows get [negative, positive, negative,
+        positive] time ids, i.e. alternating, NOT [neg, neg, pos, pos] like the prompt embeddings.  Kept as executed.
+        ``callback_on_step_end(pipe, i, t, {name: tensor})`` after every step with the tensors named in ``callback_on_step_end_tensor_inputs``
+        (``latents`` (2, C, H/8, W/8) fp32, ``prompt_embeds`` (4, 77, Cx) = [neg, neg, pos, pos], ``negative_prompt_embeds`` (2, 77, Cx)), once per request;
+        a returned ``{"latents": ...}`` replaces the request's latents for the next step (:617-626).  Returned prompt embeddings are refused (the
+        cached cross-attention K / V would have to follow).  ``callback(i, t, latents)`` every ``callback_steps`` steps (:629-632).  Callbacks switch off
+        ``dedup`` / ``stage_cache`` (they may make the two samples differ) and run between hipGraph replays.
         ``identitynet`` (InstantID, instantid_pipeline.py:638-674): ControlNet on the CONCEPT pass fed with the face tokens and
         the request's ``kps_image`` (1,3,H,W); requests then also carry ``region_image_embeds`` = [(2,16,Cx) [zero-id, id]] * K and
         the UNet must have an :class:`omg_amd.ip_adapter.IPAdapter` installed.
@@ -492,6 +511,16 @@ class LoraMultiConceptPipeline:
                     kps_l.append(r["kps_image"].to(device=dev, dtype=torch.float32))
         Ka = len(active)
         shard = concept_shard if (concept_shard is not None and concept_shard.world > 1) else None
+        has_cb = callback is not None or callback_on_step_end is not None
+        if has_cb:
+            if shard is not None:
+                raise L.OmgHipError("callbacks with concept_shard are not built: every rank would have to run the same callback")
+            bad = [k for k in callback_on_step_end_tensor_inputs if k not in _CALLBACK_TENSORS]
+            if bad:
+                raise ValueError(f"callback_on_step_end_tensor_inputs {bad}: only {list(_CALLBACK_TENSORS)} exist (lora_pipeline.py:165)")
+            if callback is not None and (callback_steps is None or int(callback_steps) <= 0):
+                raise ValueError("callback needs a positive callback_steps")
+            dedup, stage_cache, drop_unc0 = False, None, False
         if cn_multi is not None:
             if shard is not None:
                 raise L.OmgHipError("concept_shard with a list of ControlNets / guess_mode is not built: run the unsharded call")
@@ -510,8 +539,12 @@ class LoraMultiConceptPipeline:
         nm, ncn = 4 * n, 2 * Ka * n                       # rows of the main block / the concept block
         nb = nm + (ncn if fuse_possible else 0)
         ehs = torch.cat(ehs_l, dim=0).contiguous()                                                  # (4n, 77, Cx)
-        emb_main = self._all_step_embeddings(ts, torch.cat(text_l, dim=0),
-                                             self._add_time_ids(original_size, crops_coords_top_left, target_size, nm, dev))
+        tids_main = self._add_time_ids(original_size, crops_coords_top_left, target_size, nm, dev)
+        if negative_original_size is not None and negative_target_size is not None:
+            # lora_pipeline.py:459-474 as executed: cat([negative_add_time_ids, add_time_ids]).repeat(batch_size, 1) -> rows [neg, pos, neg, pos]
+            tids_neg = self._add_time_ids(negative_original_size, negative_crops_coords_top_left, negative_target_size, nm, dev)
+            tids_main = torch.where((torch.arange(nm, device=dev) % 2 == 0)[:, None], tids_neg, tids_main)
+        emb_main = self._all_step_embeddings(ts, torch.cat(text_l, dim=0), tids_main)
         slots: List[int] = []
         if fuse_possible and concept_models is None:
             raise ValueError("stage 2 needs concept_models")
@@ -588,6 +621,8 @@ class LoraMultiConceptPipeline:
             stage_cache, drop_unc0 = None, False
         if stage_cache is not None and shard is None and S > fusion_start + 1:
             common = (S, float(guidance_scale), type(self.scheduler).__name__, fusion_start, height, width, tuple(original_size),
+                      None if negative_original_size is None or negative_target_size is None else
+                      (tuple(negative_original_size), tuple(negative_crops_coords_top_left), tuple(negative_target_size)),
                       tuple(crops_coords_top_left), tuple(target_size), str(dt), tuple(main_adapters), main_scale, lora_mode if main_adapters else None,
                       id(self.unet), getattr(self.unet, "weights_version", 0), getattr(bank, "version", None) if main_adapters else None,
                       None if controller is None else (type(controller).__name__, getattr(controller, "is_pure_replacement", False),
@@ -748,7 +783,7 @@ class LoraMultiConceptPipeline:
         state_main = None
         if main_slot >= 0:
             state_main = concept_models.lora_state([main_slot + 1] * nm, merged=True) if merged else concept_models.lora_state([main_slot] * nm, merged=False)
-        tids_m = self._add_time_ids(original_size, crops_coords_top_left, target_size, nm, dev)
+        tids_m = tids_main
         if use_cn:
             eng.cn_image.copy_(controlnet_image.to(device=dev, dtype=torch.float32))
             t_all = ts.reshape(S, 1).expand(S, nm).reshape(-1).contiguous()
@@ -1015,6 +1050,23 @@ class LoraMultiConceptPipeline:
         # ---- 8. denoising loop
         for i in range(first, S):
             run_step(i)
+            if has_cb:
+                t_i = self.scheduler.timesteps[i]
+                for j in range(n):
+                    lj = lat[2 * j: 2 * j + 2]
+                    if callback_on_step_end is not None:
+                        avail = {"latents": lj, "prompt_embeds": eng.ehs[4 * j: 4 * j + 4], "negative_prompt_embeds": eng.ehs[4 * j: 4 * j + 2]}
+                        outs = dict(callback_on_step_end(self, i, t_i, {k: avail[k] for k in callback_on_step_end_tensor_inputs}) or {})
+                        new = outs.pop("latents", lj)
+                        for k_, v_ in outs.items():
+                            if k_ in avail and v_ is not avail[k_] and not torch.equal(v_.to(avail[k_]), avail[k_]):
+                                raise L.OmgHipError(f"callback_on_step_end returned a new {k_}: only `latents` can be replaced mid-loop")
+                        if new is not lj:
+                            lj.copy_(new.to(device=dev, dtype=torch.float32))
+                            if i + 1 < S:      # the step kernel wrote the next model input from ITS latents: redo it from the callback's
+                                ops.scale_model_input(lj, torch.tensor([self.scheduler.cin[i + 1]], dtype=torch.float32, device=dev), xin[4 * j: 4 * j + 4])
+                    if callback is not None and i % int(callback_steps) == 0:
+                        callback(i // getattr(self.scheduler, "order", 1), t_i, lj)
             if trajectory is not None:
                 trajectory.append(lat.clone().view(n, 2, Cl, Hl, Wl))
             if cache_keys and first == 0 and i == fusion_start:         # the latents entering the first fused step of a stage-2 call
@@ -1069,8 +1121,12 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
             # UNet without that concatenation (:580-616) — a shape error either way.  The LoRA flow's guess_mode is implemented (generate_many).
             raise L.OmgHipError("guess_mode=True: the reference's InstantID loop itself fails on it (residual batch 4 vs 2, instantid_pipeline.py:638-657); "
                                 "LoraMultiConceptPipeline implements it")
-        for dead in ("face_app", "prompt", "negative_prompt"):      # consumed by omg_amd.compat's front end when the scripts call it; dead here
-            kwargs.pop(dead, None)
+        for dead in ("face_app", "prompt", "negative_prompt", "prompt_2", "negative_prompt_2", "clip_skip"):      # consumed by omg_amd.compat's front end
+            kwargs.pop(dead, None)                                                                                 # (prompt encoding) when the scripts call it; dead here
+        neg_cond = (kwargs.pop("negative_original_size", None), kwargs.pop("negative_crops_coords_top_left", (0, 0)), kwargs.pop("negative_target_size", None))
+        callbacks = dict(callback=kwargs.pop("callback", None), callback_steps=kwargs.pop("callback_steps", None),
+                         callback_on_step_end=kwargs.pop("callback_on_step_end", None),
+                         callback_on_step_end_tensor_inputs=kwargs.pop("callback_on_step_end_tensor_inputs", ("latents",)))
         refuse_unimplemented({k: kwargs.pop(k) for k in list(kwargs) if k in _UNIMPLEMENTED}, kwargs, "InstantidMultiConceptPipeline.__call__")
         K = len(region_prompt_embeds or [])
         # stage 1 is called with image=None: no IdentityNet (instantid_pipeline.py:393, :426-428)
@@ -1090,7 +1146,9 @@ class InstantidMultiConceptPipeline(LoraMultiConceptPipeline):
                                  cross_attention_kwargs=cross_attention_kwargs, main_adapters=main_adapters,
                                  concept_adapters=concept_adapters, concept_adapter_scale=1.0, lora_mode=lora_mode,
                                  stage_cache=stage_cache, original_size=original_size, crops_coords_top_left=crops_coords_top_left,
-                                 target_size=target_size, control_guidance_start=control_guidance_start, control_guidance_end=control_guidance_end)[0]
+                                 target_size=target_size, control_guidance_start=control_guidance_start, control_guidance_end=control_guidance_end,
+                                 negative_original_size=neg_cond[0], negative_crops_coords_top_left=neg_cond[1], negative_target_size=neg_cond[2],
+                                 **callbacks)[0]
         if trajectory is not None:
             trajectory.extend(t[0] for t in traj_many)
         lat = self._postprocess(lat, output_type)

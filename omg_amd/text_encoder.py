@@ -153,9 +153,10 @@ class ClipTextEncoder(nn.Module):
         self._packed = {"layers": layers, "mask": mask, "pos": pos}
 
     @torch.no_grad()
-    def forward(self, input_ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, input_ids: torch.Tensor, clip_skip: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
         """``input_ids`` (B, 77) int64 on the device -> (hidden_states[-2] (B, 77, d), pooled (B, projection_dim or d)),
-        i.e. what diffusers' encode_prompt takes from ``text_encoder(ids, output_hidden_states=True)``."""
+        i.e. what diffusers' encode_prompt takes from ``text_encoder(ids, output_hidden_states=True)``.  ``clip_skip=k`` (lora_pipeline.py:245, :333):
+        ``hidden_states[-(k + 2)]`` instead — SDXL counts from the penultimate layer —; the pooled output is the full pass's either way."""
         cfg = self.config
         if not input_ids.is_cuda:
             raise L.OmgHipError("ClipTextEncoder runs on the HIP kernels only (no CPU fallback)")
@@ -172,9 +173,12 @@ class ClipTextEncoder(nn.Module):
         scores = torch.empty(T, T, dtype=x.dtype, device=x.device)
         penultimate = x
         n_layers = len(self.text_model.encoder.layers)
+        skip = int(clip_skip or 0)
+        if not 0 <= skip < n_layers:
+            raise ValueError(f"clip_skip={clip_skip}: this encoder has {n_layers} layers")
         for li, (lyr, w) in enumerate(zip(self.text_model.encoder.layers, pk["layers"])):
-            if li == n_layers - 1:
-                penultimate = x                                     # hidden_states[-2] = the input of the last layer
+            if li == n_layers - 1 - skip:
+                penultimate = x                                     # hidden_states[-(2 + skip)] = the input of layer n - 1 - skip
             h = lyr.layer_norm1(x)
             qkv = ops.gemm(h, w["wqkv"], bias=w["bqkv"]).view(B, T, 3 * d)
             vt = ops.transpose_v(qkv[:, :, 2 * d:], heads, mfma_order=False)   # (B, heads, 64, 128), plain transpose
@@ -201,10 +205,11 @@ class ClipTextEncoder(nn.Module):
 
 
 @torch.no_grad()
-def encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, ids_l: torch.Tensor, ids_g: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, ids_l: torch.Tensor, ids_g: torch.Tensor,
+                  clip_skip: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """SDXL's two-encoder embedding: (B, 77, 2048) and the pooled (B, 1280) of the second encoder."""
-    hl, _ = enc_l(ids_l)
-    hg, pooled = enc_g(ids_g)
+    hl, _ = enc_l(ids_l, clip_skip)
+    hg, pooled = enc_g(ids_g, clip_skip)
     return torch.cat([hl, hg], dim=-1), pooled
 
 
@@ -214,6 +219,10 @@ def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_
     diffusers' ``StableDiffusionXLPipeline.encode_prompt`` returns them (lora_pipeline.py:315-347).  ``tokenize_*`` map a list of
     strings to (B, 77) int64 ids (the reference's ``pipe.tokenizer`` / ``pipe.tokenizer_2`` with ``padding="max_length"``).  A
     ``None`` negative prompt gives zero embeddings (SDXL-base ships ``force_zeros_for_empty_prompt=True``).
+
+    Round 6: ``prompt_2`` / ``negative_prompt_2`` (lora_pipeline.py:215, :222: the SECOND encoder's own prompt, default = the first's) and
+    ``clip_skip`` (:245, :333) as diffusers' ``encode_prompt`` takes them; like there, ``clip_skip`` moves the POSITIVE prompt's hidden state
+    only — the negative prompt is always read at ``hidden_states[-2]`` (diffusers 0.25.0, recalled).
 
     ``lora_param``: the adapters active on the text encoders while this prompt is encoded — ``None``, an adapter name, or
     [(name, weight), ...] (the reference calls ``concept_models.set_adapters(lora)`` / ``set_adapters([lora, "style"], [0.7, 0.5])``
@@ -229,7 +238,7 @@ def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_
         out = [p] if isinstance(p, str) else list(p)
         return out * n if len(out) == 1 and n > 1 else out
 
-    def fn(prompt, negative_prompt=None, lora_param=None, lora_scale=None):
+    def fn(prompt, negative_prompt=None, lora_param=None, lora_scale=None, prompt_2=None, negative_prompt_2=None, clip_skip=None):
         combo = [] if lora_param is None else [(lora_param, 1.0)] if isinstance(lora_param, str) else list(lora_param)
         ls = 1.0 if lora_scale is None else float(lora_scale)
         for n_te, enc in ((1, enc_l), (2, enc_g)):
@@ -243,14 +252,18 @@ def make_encode_prompt(enc_l: ClipTextEncoder, enc_g: ClipTextEncoder, tokenize_
             enc.set_lora(act)
         try:
             prompts = _list(prompt, 1)
+            prompts_2 = _list(prompt_2, len(prompts)) if prompt_2 is not None else prompts
+            if len(prompts_2) != len(prompts):
+                raise ValueError("prompt_2 must be one string or one per prompt")
             dev = enc_l.device
-            pe, pp = encode_prompt(enc_l, enc_g, tokenize_l(prompts).to(dev), tokenize_g(prompts).to(dev))
-            if negative_prompt is None:
+            pe, pp = encode_prompt(enc_l, enc_g, tokenize_l(prompts).to(dev), tokenize_g(prompts_2).to(dev), clip_skip)
+            if negative_prompt is None and negative_prompt_2 is None:
                 return pe, torch.zeros_like(pe), pp, torch.zeros_like(pp)
-            negs = _list(negative_prompt, len(prompts))
-            if len(negs) != len(prompts):
-                raise ValueError("negative_prompt must be one string or one per prompt")
-            ne, npp = encode_prompt(enc_l, enc_g, tokenize_l(negs).to(dev), tokenize_g(negs).to(dev))
+            negs = _list(negative_prompt if negative_prompt is not None else "", len(prompts))
+            negs_2 = _list(negative_prompt_2, len(prompts)) if negative_prompt_2 is not None else negs
+            if len(negs) != len(prompts) or len(negs_2) != len(prompts):
+                raise ValueError("negative_prompt / negative_prompt_2 must be one string or one per prompt")
+            ne, npp = encode_prompt(enc_l, enc_g, tokenize_l(negs).to(dev), tokenize_g(negs_2).to(dev))
             return pe, ne, pp, npp
         finally:
             enc_l.set_lora(None)

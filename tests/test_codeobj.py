@@ -48,7 +48,7 @@ def test_the_16_bit_gemm_instances_of_the_256_tile_use_no_scratch_at_all(ks):
 
 
 def test_attention_kernels_fit_two_workgroups_per_cu_without_scratch(ks):
-    for name in ("attn_fwd_kernel7", "attn_fwd_kernel3", "attn_fwd_kernel6", "attn_fwd_kernel2"):
+    for name in ("attn_fwd_kernel7", "attn_fwd_kernel6", "attn_fwd_kernel2"):
         inst = pick(ks, name)
         assert len(inst) == 2, (name, list(inst))         # f16 and bf16
         for n, k in inst.items():
@@ -67,7 +67,7 @@ def test_scratch_users_are_known_and_small(ks):
             assert fam and sz <= allowed[fam[0]], (n, sz)
 
 
-@pytest.mark.parametrize("family", ["gemm_kernel_v12", "gemm_kernel_v13", "gemm_kernel_v7", "gemm_mx8_kernel", "attn_fwd_kernel7", "attn_fwd_kernel3", "attn_fwd_kernel6"])
+@pytest.mark.parametrize("family", ["gemm_kernel_v12", "gemm_kernel_v13", "gemm_kernel_v7", "gemm_mx8_kernel", "attn_fwd_kernel7", "attn_fwd_kernel6"])
 def test_no_scratch_access_between_the_first_and_the_last_mfma(family):
     """Where the spilled registers of the table above are touched: never inside the MFMA region (K loop / key-tile loop).  A scratch
     reload there would wait on vmcnt and with it on the LDS-DMA of the next stage (any scratch use in a one-block-per-CU
@@ -132,14 +132,18 @@ def test_the_256x320_tile_keeps_every_accumulator_where_the_source_pins_it(ks):
 
 
 def test_the_row_major_v_attention_reads_v_through_the_transposing_lds_read(ks):
-    """attn_fwd_kernel7 (csrc/attn_v7.h) = v3 with the V tile staged row-major and transposed on the way out of LDS.  It reads every V^T fragment
-    with two ds_read_b64_tr_b16 — 16 per key tile, in each of the three copies of the tile body (first tile, steady state, ragged tail) — where v3
-    has eight ds_read_b128; the K fragments stay on ds_read_b128; no 16-register copies of the reference-maximum splat in front of the tile's MFMAs."""
+    """attn_fwd_kernel7 (csrc/attn_v7.h): the V tile staged row-major and transposed on the way out of LDS.  It reads every V^T fragment with two
+    ds_read_b64_tr_b16 — 16 per key tile, in each of the three copies of the tile body (first tile, steady state, ragged tail) — where a V^T image
+    took eight ds_read_b128; the K fragments stay on ds_read_b128; no 16-register copies of the reference-maximum splat in front of the tile's MFMAs.
+    Round 6: per tile body 32 algorithmic 32 x 32 x 16 MFMAs + 8 16 x 16 x 32 ones for the softmax denominator (was 40 of the large shape)."""
     v7 = pick(ks, "attn_fwd_kernel7")
     assert len(v7) == 2                                  # f16 / bf16
     for n, ins in _codeobj.disassembly(LIB, "attn_fwd_kernel7").items():
         assert ins.count("ds_read_b64_tr_b16") == 48 and ins.count("ds_read_b128") == 24, (n, ins.count("ds_read_b64_tr_b16"), ins.count("ds_read_b128"))
-        assert ins.count("v_mov_b64_e32") <= 64 and ins.count("v_mov_b32_e32") <= 200, (n, ins.count("v_mov_b64_e32"), ins.count("v_mov_b32_e32"))
+        assert ins.count("v_mov_b64_e32") <= 64 and ins.count("v_mov_b32_e32") <= 220, (n, ins.count("v_mov_b64_e32"), ins.count("v_mov_b32_e32"))
+        big = sum(1 for x in ins if x.startswith("v_mfma_f32_32x32x16"))
+        small = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32"))
+        assert (big, small) == (96, 24), (n, big, small)
 
 
 def test_conv_out_pixel_kernel_takes_its_weights_through_the_scalar_cache(ks):

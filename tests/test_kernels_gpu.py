@@ -220,9 +220,11 @@ def test_attention(dev, dtype, B, heads, Nq, Nkv):
     # adversarial rows: one dominant logit, and an all-equal-logits query
     q[0, 0] = 0
     q[0, 1] = k[0, min(5, Nkv - 1)] * 4
-    vt = ops.transpose_v(v, heads)
-    out = ops.attention(q, k, vt, heads, 0.125)
-    close(out, attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+    q[0, 2] = k[0, Nkv - 3] * 4                   # a dominant logit in the LAST key tile: a rescale with row sums pending on the matrix pipe
+    out = ops.attention(q, k, ops.value_operand(v, heads), heads, 0.125)      # the product's operand choice: row-major V above 128 keys, V^T below
+    ref = attn_ref(q, k, v, heads, 0.125)
+    close(out, ref, dtype, scale=2.0)
+    close(ops.attention(q, k, ops.transpose_v(v, heads), heads, 0.125), ref, dtype, scale=2.0)      # a V^T image at any key count (v6 / v2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -277,71 +279,39 @@ def test_kv_resident_cross_attention_is_bitwise_the_per_block_kernel(dev, dtype,
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 3, 300, 256), (2, 2, 1024, 1000), (1, 2, 512, 4096), (3, 1, 100, 130), (2, 4, 1024, 1024)])
-def test_row_major_v_attention_is_bitwise_the_transposed_v_kernel(dev, dtype, B, heads, Nq, Nkv):
+def test_row_major_v_self_attention_kernel(dev, dtype, B, heads, Nq, Nkv):
     """attn_fwd_kernel7 (csrc/attn_v7.h; omg_attn_args.V, ABI 6): V read ROW-MAJOR — a view of the fused QKV projection's output, no
-    omg_transpose_v — through ds_read_b64_tr_b16 runs v3's arithmetic in v3's order: plain, with borrowed Q,K, and accumulating; whole tiles,
-    a ragged last tile (1000, 130: the staged rows past Nkv repeat the last key and their probabilities are zeroed), one long row of 64 tiles,
-    and a grid whose size is a multiple of 8 (the XCD-aware block order is a permutation of the blocks: the last case) or not (the others)."""
+    omg_transpose_v — through ds_read_b64_tr_b16; the softmax denominator on the 16 x 16 x 32 MFMA in an accumulator that lives across all tiles
+    (round 6).  Plain, with borrowed Q,K, and accumulating; whole tiles, a ragged last tile (1000, 130: the staged rows past Nkv repeat the last key
+    and their probabilities are zeroed), one long row of 64 tiles, a grid whose size is a multiple of 8 (the XCD-aware block order is a permutation
+    of the blocks: the last case) or not; rows that force the rescale branch in a LATE tile (the matrix-pipe partial sum is folded into the
+    lane-local one there).  Against the fp32 reference, and against the generic per-128-row kernel (v2, on a V^T image: a different summation
+    order of the same rounded probabilities) to two 16-bit ulps.  Until round 6 this test was `torch.equal` with attn_fwd_kernel3, the same loop
+    on a V^T image with round 3's 32-row ones MFMA; both went when the denominator changed (profiles/r06_attn_bench_den_forms.log)."""
     Cc = heads * 64
     qkv = rnd(B, max(Nq, Nkv), 3 * Cc, dtype=dtype, dev=dev, scale=1.2)          # V as the product has it: the last third of a fused projection
     q, k, v = qkv[:, :Nq, :Cc], qkv[:, :Nkv, Cc:2 * Cc], qkv[:, :Nkv, 2 * Cc:]
-    vt = ops.transpose_v(v, heads)                                               # a V^T image sends ops.attention to attn_fwd_kernel3
-    vr = ops.value_operand(v, heads)
-    assert isinstance(vr, ops.RowMajorV)
-    src = torch.tensor([max(0, b - 1) for b in range(B)], dtype=torch.int32, device=dev)
-    res = {}
-    from omg_amd import _lib as L
-    try:
-        for name, operand in (("v3", vt), ("v7", vr)):
-            L.lib().omg_debug_set_attn_variant(7 if name == "v7" else 0)      # 7 = v7 with round 3's denominator form, the one v3 has
-            a = ops.attention(q, k, operand, heads, 0.125)
-            b_ = ops.attention(q, k, operand, heads, 0.125, qk_src=src)
-            c = a.clone()
-            ops.attention(q, k, operand, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
-            res[name] = (a, b_, c)
-    finally:
-        L.lib().omg_debug_set_attn_variant(0)
-    for x, y in zip(res["v3"], res["v7"]):
-        assert torch.equal(x, y), (x.float() - y.float()).abs().max().item()
-    close(res["v7"][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,heads,Nq,Nkv", [(2, 3, 300, 256), (2, 2, 1024, 1000), (1, 2, 512, 4096), (3, 1, 100, 130), (2, 4, 1024, 1024)])
-def test_attention_denominator_forms_agree(dev, dtype, B, heads, Nq, Nkv):
-    """attn_fwd_kernel7<T, DEN> (csrc/attn_v7.h, round 6): the row sums of P by a 32-row ones MFMA (0, round 3's form), by the 16 x 16 x 32 MFMA into a
-    persistent 4-register accumulator (1) or by fp32 adds of the exponentials (2).  Every form against the fp32 reference, and the forms against each
-    other to two 16-bit ulps: 0 and 1 sum the ROUNDED probabilities in a different order, 2 sums the unrounded ones.  Rows that force the rescale
-    branch in a LATE tile (form 1 folds its matrix-pipe partial sum into the lane-local one there) are planted."""
-    from omg_amd import _lib as L
-    Cc = heads * 64
-    qkv = rnd(B, max(Nq, Nkv), 3 * Cc, dtype=dtype, dev=dev, scale=1.2)
-    q, k, v = qkv[:, :Nq, :Cc], qkv[:, :Nkv, Cc:2 * Cc], qkv[:, :Nkv, 2 * Cc:]
     q[0, 0] = 0                                   # all logits equal
     q[0, 1] = k[0, 5] * 4                         # dominant logit in the first tile
-    q[0, 2] = k[0, Nkv - 3] * 4                   # ... in the last (possibly ragged) tile: a rescale with sums pending
-    q[0, 40] = k[0, Nkv // 2 + 1] * 3             # ... in the middle, another query block of the same wave
+    q[0, 2] = k[0, Nkv - 3] * 4                   # ... in the last (possibly ragged) tile
+    q[0, 40] = k[0, Nkv // 2 + 1] * 3             # ... in the middle, the other query block of the same wave
+    vt = ops.transpose_v(v, heads)                                               # a V^T image above 128 keys runs the generic kernel (v2)
     vr = ops.value_operand(v, heads)
     assert isinstance(vr, ops.RowMajorV)
     src = torch.tensor([max(0, b - 1) for b in range(B)], dtype=torch.int32, device=dev)
     res = {}
-    try:
-        for var in (7, 8, 9):
-            L.lib().omg_debug_set_attn_variant(var)
-            a = ops.attention(q, k, vr, heads, 0.125)
-            b_ = ops.attention(q, k, vr, heads, 0.125, qk_src=src)
-            c = a.clone()
-            ops.attention(q, k, vr, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
-            res[var] = (a, b_, c)
-    finally:
-        L.lib().omg_debug_set_attn_variant(0)
-    ref = attn_ref(q, k, v, heads, 0.125)
+    for name, operand in (("v2", vt), ("v7", vr)):
+        a = ops.attention(q, k, operand, heads, 0.125)
+        b_ = ops.attention(q, k, operand, heads, 0.125, qk_src=src)
+        c = a.clone()
+        ops.attention(q, k, operand, heads, 0.125, out=c, accumulate=True, out_scale=0.8)
+        res[name] = (a, b_, c)
     ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
-    for var in (7, 8, 9):
-        close(res[var][0], ref, dtype, scale=2.0)
-        for x, y in zip(res[7], res[var]):
-            d = (x.float() - y.float()).abs()
-            assert bool((d <= 2 * ulp * x.float().abs() + 1e-6).all()), (var, d.max().item())
+    for x, y in zip(res["v2"], res["v7"]):
+        d = (x.float() - y.float()).abs()
+        assert bool((d <= 2 * ulp * x.float().abs() + 2e-6).all()), d.max().item()
+    close(res["v7"][0], attn_ref(q, k, v, heads, 0.125), dtype, scale=2.0)
+    close(res["v7"][1], attn_ref(q, k, v, heads, 0.125, qk_src=src.tolist()), dtype, scale=2.0)
 
 
 def test_row_major_v_is_refused_where_no_kernel_reads_it(dev):
@@ -421,6 +391,27 @@ def test_conv_in_out(dev, dtype):
     z = ops.conv_out(f, wo.permute(0, 2, 3, 1).contiguous(), bo)
     zref = F.conv2d(f.float().cpu().permute(0, 3, 1, 2), wo.float().cpu(), bo.float().cpu(), padding=1)
     torch.testing.assert_close(z.cpu(), zref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,bias", [(2, 24, 20, 320, 4, False), (1, 16, 16, 336, 3, True), (2, 9, 7, 64, 4, True), (1, 5, 5, 8, 1, True),
+                                                 (1, 16, 16, 320, 4, True), (1, 12, 12, 128, 3, False)])
+def test_conv_out_shapes(dev, dtype, B, H, W, Cin, Cout, bias):
+    """omg_conv_out has two kernels — conv_out_pixel_kernel (16-bit, Cout == 4, Cin % 32 == 0, 16-byte-aligned operands: the UNet's last
+    convolution) and the per-wave conv_out_kernel (everything else: the VAE's 3-channel output, small Cin, unaligned views).  Both, with and without a
+    bias, a pixel count that is an exact multiple of the pixel kernel's 256-lane blocks (1 x 16 x 16) and ones that are not, against F.conv2d."""
+    f = rnd(B, H, W, Cin, dtype=dtype, dev=dev)
+    wo = rnd(Cout, Cin, 3, 3, dtype=dtype, dev=dev, scale=(9 * Cin) ** -0.5, seed=1)
+    bo = rnd(Cout, dtype=dtype, dev=dev, seed=2) if bias else None
+    z = ops.conv_out(f, wo.permute(0, 2, 3, 1).contiguous(), bo)
+    zref = F.conv2d(f.float().cpu().permute(0, 3, 1, 2), wo.float().cpu(), bo.float().cpu() if bias else None, padding=1)
+    torch.testing.assert_close(z.cpu(), zref, rtol=1e-4, atol=1e-4)
+    if Cout == 4 and Cin % 32 == 0:      # the same call on operands 8 bytes off a 16-byte boundary: the dispatch must fall back, the values must not change
+        fb = torch.empty(f.numel() + 4, dtype=dtype, device=dev)[4:].view_as(f).copy_(f)
+        wsrc = wo.permute(0, 2, 3, 1).contiguous()
+        wb = torch.empty(wsrc.numel() + 4, dtype=dtype, device=dev)[4:].view_as(wsrc).copy_(wsrc)
+        assert fb.data_ptr() % 16 == 8 and wb.data_ptr() % 16 == 8
+        torch.testing.assert_close(ops.conv_out(fb, wb, bo).cpu(), zref, rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

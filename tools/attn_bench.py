@@ -21,7 +21,7 @@ def timeit(fn, iters=30, warm=10):
 dev, dt = torch.device("cuda:0"), torch.float16
 lib = L.lib()
 VARS = tuple(int(a, 0) for a in sys.argv[1:]) or (0,)
-print("# variants", VARS, "(0 = the heuristic: v7 above 128 keys — V row-major, no transpose_v — v6 / v2 below; 2 = v2; 3 = v3 on the V^T image (+ the transpose_v pass it needs, timed separately); 6 = v6; 7 = v7)"
+print("# variants", VARS, "(0 = the heuristic: v7 above 128 keys — V row-major, no transpose_v — v6 / v2 below; 2 = v2 on the V^T image (+ the transpose_v pass it needs, timed separately); 6 = v6; 7 = v7)"
       " — OMG_HIP_LIB=<other build> runs the same table on another library for A/B")
 print("# q, k, v are the three column slices of ONE fused (B, N, 3C) projection output, as the UNet has them")
 print("# (B, heads, Nq, Nkv): TF/s per variant; max |last - first variant|")
@@ -42,7 +42,7 @@ for (B, heads, Nq, Nkv) in [(64, 10, 4096, 4096), (64, 20, 1024, 1024), (64, 20,
     fl = 4.0 * B * heads * Nq * Nkv * 64
     res, outs = [], []
     for var in VARS:
-        operand = vr if var in (0, 7, 8, 9) else vt      # 7 / 8 / 9: v7 with the denominator form 0 / 1 / 2 (csrc/attn_v7.h)
+        operand = vr if var in (0, 7) else vt
         lib.omg_debug_set_attn_variant(var)
         ms = timeit(lambda: ops.attention(q, k, operand, heads, 0.125, out=out))
         res.append(fl / ms / 1e9)
