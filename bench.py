@@ -363,7 +363,7 @@ def main():
         # shape by tools/pmc_traffic.py (method and gfx950 correction recorded in the file) is reported — the newest round's file
         traffic, traffic_note = None, "no PMC measurement committed"
         tag = "fp8" if args.dtype == "fp8" else "fp16"
-        tfile = next((f for f in (f"r05_pmc_traffic_{tag}.json", f"r04_pmc_traffic_{tag}.json", f"r03_pmc_traffic_{tag}.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
+        tfile = next((f for f in (f"r06_pmc_traffic_{tag}.json", f"r05_pmc_traffic_{tag}.json", f"r04_pmc_traffic_{tag}.json", f"r03_pmc_traffic_{tag}.json") if os.path.exists(os.path.join(ROOT, "profiles", f))), "")
         try:      # tools/pmc_traffic.py wrote it from rocprofv3 --pmc passes of the kernel this line's roofline names
             with open(os.path.join(ROOT, "profiles", tfile)) as f:
                 pm = json.load(f)

@@ -457,9 +457,11 @@ def test_fifty_step_trajectory_error_growth(dev, dtype):
     # how far the REFERENCE's arithmetic drifts from fp32 truth over the loop, and how far the HIP path is from it
     # (fp16 — the reference's dtype — only: the emulated loop is another ~95 s of host time per dtype; the bf16 curve of round 4 is committed
     # as profiles/r04_error_growth_bf16.json: bf16 oracle vs fp32 oracle 7.2e-2, HIP vs bf16 oracle 8.7e-2 at the worst step)
+    # Round 6: the emulated twin (another ~95 s of host oracle) runs under OMG_RUN_SLOW=1 only — its curve is committed (profiles/r04_error_growth_fp16.json,
+    # r05_..., and at full width r06_config0_fullwidth_loop.json); the driver's `-m gpu` keeps the fp32 comparison and its bound
     from oracle import precision as oprec
     rel_o = rel_h = None
-    if dtype == torch.float16:
+    if dtype == torch.float16 and os.environ.get("OMG_RUN_SLOW") == "1":
         octl.reset()
         rec16 = []
         with oprec.rounding(dtype):

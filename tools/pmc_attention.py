@@ -5,6 +5,8 @@
 
 MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); a 32x32x16 MFMA is 32 busy cycles.  FETCH_SIZE is
 doubled for gfx950 (MI355X_MICROARCH.md).  Counter runs clock lower than un-profiled ones: ratios, not times, are the result.
+Round 6: the self-attention kernel's softmax denominator is eight 16x16x32 MFMAs per wave and key tile beside the 32 algorithmic 32x32x16 ones; `mfma_instructions`
+(= busy cycles / 32) therefore counts 32x32x16 EQUIVALENTS (round 5: 40 per tile, now 32 + 8 x the smaller shape's busy cycles / 32).
 """
 import csv
 import glob
@@ -32,7 +34,7 @@ def one_pass(counters, cmd, match):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_pmc_attention.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_pmc_attention.json")
     sq = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_LDS"]
     rec = {"method": __doc__}
     for name, shape, match in (("self", (64, 10, 4096, 4096), "attn_fwd_kernel7"), ("cross", (64, 20, 1024, 77), "attn_fwd_kernel6")):

@@ -1,4 +1,5 @@
 """PMC view of the 16-bit GEMM at the benchmark's shapes (GPU box only):   python tools/pmc_gemm.py [out.json]
+                                                                         python tools/pmc_gemm.py mx8 [out.json]     (round 6: gemm_mx8_kernel, fresh)
 
 One rocprofv3 pass per shape with the SQ counters that fit together (MI355X_MICROARCH.md, PMC slots): SQ_VALU_MFMA_BUSY_CYCLES,
 GRBM_GUI_ACTIVE, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_WAIT_ANY, SQ_ACTIVE_INST_ANY, SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE — for the product
@@ -28,19 +29,29 @@ def one_pass(counters, cmd, match):
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_pmc_gemm.json")
+    argv = sys.argv[1:]
+    mx8 = bool(argv) and argv[0] == "mx8"
+    if mx8:
+        argv = argv[1:]
+    out = argv[0] if argv else os.path.join(ROOT, "profiles", "r06_pmc_mx8.json" if mx8 else "r06_pmc_gemm.json")
     rec = {"method": __doc__, "shapes": {}}
+    # gemm_mx8_kernel: v_mfma_scale_f32_32x32x64_f8f6f4 is 64 busy cycles per instruction and 2 x 32 x 32 x 64 FLOP
+    kname, busy, kdepth = ("gemm_mx8_kernel", 64.0, 64) if mx8 else ("gemm_kernel_v12", 32.0, 16)
+    if mx8:
+        rec["method"] += ("\nmx8 mode: tools/mx8_one.py; SQ_VALU_MFMA_BUSY_CYCLES = 64 per v_mfma_scale_f32_32x32x64_f8f6f4, so MfmaUtil is against the fp8 "
+                          "matrix peak (5 PFLOP/s at 2.4 GHz).")
     for M, N, K, geglu in ((65536, 10240, 1280, True), (65536, 1280, 5120, False), (8192, 8192, 8192, False)):
-        cmd = [sys.executable, "tools/gemm_one.py", str(M), str(N), str(K), "25", "4"] + (["geglu"] if geglu else [])
-        d, names = one_pass(SQ, cmd, "gemm_kernel_v12")
+        cmd = ([sys.executable, "tools/mx8_one.py", str(M), str(N), str(K), "4"] if mx8 else
+               [sys.executable, "tools/gemm_one.py", str(M), str(N), str(K), "25", "4"]) + (["geglu"] if geglu else [])
+        d, names = one_pass(SQ, cmd, kname)
         if not d:
-            raise SystemExit("no dispatch of gemm_kernel_v12 in the counter collection")
+            raise SystemExit(f"no dispatch of {kname} in the counter collection")
         c = d[-1]
         wc = c["SQ_WAVE_CYCLES"]
         rec["shapes"][f"{M}x{N}x{K}" + (" geglu" if geglu else "")] = {
             "kernel": names, "counters_last_dispatch": c,
             "mfma_util": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 128.0),
-            "mfma_instructions": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 32.0, "algorithmic_mfma_instructions": 2.0 * M * N * K / (2.0 * 32 * 32 * 16),
+            "mfma_instructions": c["SQ_VALU_MFMA_BUSY_CYCLES"] / busy, "algorithmic_mfma_instructions": 2.0 * M * N * K / (2.0 * 32 * 32 * kdepth),
             "wait_inst_any_share": c["SQ_WAIT_INST_ANY"] / wc, "wait_any_share": c["SQ_WAIT_ANY"] / wc, "active_inst_any_share": c["SQ_ACTIVE_INST_ANY"] / wc,
             "lds_bank_conflict_share_of_lds_cycles": c["SQ_LDS_BANK_CONFLICT"] / max(1.0, c["SQ_LDS_IDX_ACTIVE"])}
     with open(out, "w") as fh:
