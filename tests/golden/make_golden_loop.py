@@ -423,6 +423,8 @@ CASES = [  # name, scheduler, steps, guidance, mask kind, styleL, (latent h, lat
     ("ddim_controlnet_window", "ddim", 18, 7.5, "overlap", False, (16, 16), "lora_cn_window"),
     ("ddim_controlnet_guess", "ddim", 18, 7.5, "overlap", False, (16, 16), "lora_cn_guess"),
     ("euler_controlnet_multi", "euler", 18, 7.5, "none_mid", False, (16, 16), "lora_cn_multi"),
+    # instantid_pipeline.py:477-483, :566-578: the ONE guidance window scales the IdentityNet (concept rows) AND the t2i ControlNet (main rows)
+    ("euler_instantid_t2i_window", "euler", 20, 3.0, "overlap", False, (16, 16), "iid_t2i_window"),
     # instantid_pipeline.py:540-707: IdentityNet (key-point image + face tokens) and the IP-Adapter branch on the concept rows, guidance 3
     # (inference_instantid.py:78); `iid_t2i`: + a second ControlNet (self.controlnet2, t2i_image) on the main rows (:574-592)
     ("euler_instantid", "euler", 18, 3.0, "overlap", False, (16, 16), "iid"),
@@ -432,7 +434,9 @@ LORA_RANK, LORA_SEED0, LORA_SCALE = 8, 100, 0.8
 CN_SCALE, IDN_SCALE, T2I_SCALE, IP_SCALE, IP_TOKENS, FACE_DIM = 0.7, 0.8, 0.6, 0.8, 16, 512
 CN_VARIANTS = {"lora_cn": {}, "lora_cn_window": dict(control_guidance_start=0.2, control_guidance_end=0.7), "lora_cn_guess": dict(guess_mode=True),
                # two nets: the second one's own image, scale and window; both act in steps 6..9 of 18
-               "lora_cn_multi": dict(control_guidance_start=[0.0, 0.3], control_guidance_end=[0.6, 1.0])}
+               "lora_cn_multi": dict(control_guidance_start=[0.0, 0.3], control_guidance_end=[0.6, 1.0]),
+               # 20 steps: both nets act in steps 4..17 — the first two fused steps (16, 17) with, the last two (18, 19) without the IdentityNet
+               "iid_t2i_window": dict(control_guidance_start=0.2, control_guidance_end=0.9)}
 RESAMPLER = dict(dim=1280, depth=4, dim_head=64, heads=20, num_queries=IP_TOKENS, embedding_dim=FACE_DIM)      # instantid_single_pieline.py:163-174
 
 
@@ -598,7 +602,8 @@ def run_reference_instantid(c):
     controller = AttentionReplace(*c["ctl_args"], tokenizer=WhitespaceTokenizer(), device="cpu", dtype=torch.float32)
     revise_regionally_controlnet_forward(pipe.unet, controller)
     out = {"num_att_layers": np.array(controller.num_att_layers)}
-    t2i = c["pose2"] if c["flow"] == "iid_t2i" else None
+    t2i = c["pose2"] if c["flow"].startswith("iid_t2i") else None
+    cn_kw = dict(CN_VARIANTS.get(c["flow"], {}))
     for stage in (1, 2):
         controller.reset()
         traj = []
@@ -613,7 +618,7 @@ def run_reference_instantid(c):
                    image=[c["pose"]] if stage == 2 else None, height=c["H"], width=c["W"], num_inference_steps=c["steps"], guidance_scale=c["gs"],
                    latents=c["lat0"].clone(), cross_attention_kwargs={"scale": LORA_SCALE}, controller=controller, concept_models=concept,
                    face_app=face_app, stage=stage, region_masks=c["masks"], controlnet_conditioning_scale=IDN_SCALE,
-                   t2i_image=t2i, t2i_controlnet_conditioning_scale=T2I_SCALE, output_type="latent")
+                   t2i_image=t2i, t2i_controlnet_conditioning_scale=T2I_SCALE, output_type="latent", **cn_kw)
         pipe.scheduler.step = real_step
         assert torch.equal(res.images, traj[-1])
         assert (controller.cur_step, controller.cur_att_layer) == (c["steps"], 0)
@@ -621,6 +626,9 @@ def run_reference_instantid(c):
     out["set_adapters_calls"] = np.array(0)
     out["controlnet_calls"] = np.array(idn.calls)
     out["controlnet2_calls"] = np.array(pipe.controlnet2.calls)
+    if cn_kw:      # the conditioning_scale every call of the two nets saw (IdentityNet: stage 2's fused steps, once per masked concept; t2i: every step of both stages)
+        out["controlnet_scales_seen"] = np.array(idn.scales_seen)
+        out["controlnet2_scales_seen"] = np.array(pipe.controlnet2.scales_seen)
     return out
 
 

@@ -254,7 +254,7 @@ def test_controlnet_keep_is_the_reference_s_schedule():
     gold = np.load(os.path.join(gold_dir, "loop_golden.npz"))
     for case in mk.CASES:
         name, steps, flow = case[0], case[2], case[7]
-        if f"{name}/controlnet_scales_seen" not in gold.files:
+        if f"{name}/controlnet_scales_seen" not in gold.files or not flow.startswith("lora_cn"):
             continue
         seen = gold[f"{name}/controlnet_scales_seen"]                     # (nets, 2 stages x steps)
         kw = mk.CN_VARIANTS[flow]
@@ -262,6 +262,10 @@ def test_controlnet_keep_is_the_reference_s_schedule():
         sc = [mk.CN_SCALE, mk.T2I_SCALE][: seen.shape[0]]
         want = np.array([[sc[k] * keep[i][k] for i in range(steps)] * 2 for k in range(seen.shape[0])])
         assert np.array_equal(seen, want), name
+    # the InstantID twin: ONE window for the IdentityNet and the t2i ControlNet (instantid_pipeline.py:477-483, :566-578)
+    kw = mk.CN_VARIANTS["iid_t2i_window"]
+    keep = [k_[0] for k_ in controlnet_keep(20, kw["control_guidance_start"], kw["control_guidance_end"], 1)]
+    assert np.array_equal(gold["euler_instantid_t2i_window/controlnet2_scales_seen"], np.array([mk.T2I_SCALE * k_ for k_ in keep] * 2))
     # scalars broadcast to every net; a scalar start beside a list of ends (and the other way round) as :275-279
     assert controlnet_keep(4, 0.0, 1.0, 3) == [[1.0] * 3] * 4
     assert controlnet_keep(4, 0.5, [1.0, 0.75]) == [[0.0, 0.0], [0.0, 0.0], [1.0, 1.0], [1.0, 0.0]]

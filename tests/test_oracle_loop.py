@@ -65,11 +65,12 @@ def oracle_run(c, stage, num_att_layers):
         down = mid = None
         if flow.startswith("lora_cn"):
             down, mid = opipe.main_controlnet_residuals(nets, x, i, ctx4, te4, tid.repeat(4, 1), images, scales, keep[i], cn_kw.get("guess_mode", False))
-        if flow == "iid_t2i":        # instantid_pipeline.py:574-592: self.controlnet2 on the main rows with t2i_image
-            down, mid = ocn.controlnet_forward(c["csd2"], cfg, x, t, ctx4, c["pose2"].repeat(4, 1, 1, 1), mk.T2I_SCALE, te4, tid.repeat(4, 1))
+        if flow.startswith("iid_t2i"):        # instantid_pipeline.py:574-592: self.controlnet2 on the main rows with t2i_image, scale x controlnet_keep[i] (:578)
+            down, mid = ocn.controlnet_forward(c["csd2"], cfg, x, t, ctx4, c["pose2"].repeat(4, 1, 1, 1), mk.T2I_SCALE * iid_keep[i][0], te4, tid.repeat(4, 1))
         return ou.unet_forward(sd, cfg, x, t, ctx4, te4, tid.repeat(4, 1), attn_fn=attn, lora=main_lora,
                                down_block_additional_residuals=down, mid_block_additional_residual=mid)
 
+    iid_keep = opipe.controlnet_keep(S, cn_kw.get("control_guidance_start", 0.0), cn_kw.get("control_guidance_end", 1.0), 1)
     if flow.startswith("iid"):
         ip_fn = oip.make_ip_attn_fn(c["ipw"], mk.IP_SCALE, mk.IP_TOKENS)
         # instantid_single_pieline.py:221-243: [zeros | face embedding] through the Resampler -> (2, 16, D) image-prompt tokens
@@ -85,7 +86,7 @@ def oracle_run(c, stage, num_att_layers):
         if flow.startswith("iid"):
             def f(x, i):             # instantid_pipeline.py:638-674: IdentityNet(latents, face tokens, key points) -> concept UNet(text + face tokens), no LoRA scale
                 t = float(osch.timesteps[i])
-                down, mid = ocn.controlnet_forward(c["csd"], cfg, x, t, faces[k], c["pose"].repeat(2, 1, 1, 1), mk.IDN_SCALE, te2, tid.repeat(2, 1))
+                down, mid = ocn.controlnet_forward(c["csd"], cfg, x, t, faces[k], c["pose"].repeat(2, 1, 1, 1), mk.IDN_SCALE * iid_keep[i][0], te2, tid.repeat(2, 1))      # :566-572
                 return ou.unet_forward(sd, cfg, x, t, torch.cat([ctx2, faces[k]], dim=1), te2, tid.repeat(2, 1), attn_fn=ip_fn,
                                        down_block_additional_residuals=down, mid_block_additional_residual=mid)
             return f
@@ -129,7 +130,13 @@ def test_oracle_loop_matches_the_reference_pipeline_run_here(gold, case):
     if c["flow"].startswith("iid"):      # the InstantID loop never selects adapters; IdentityNet once per masked concept per fused step (stage 2 only)
         assert int(gold[f"{c['name']}/set_adapters_calls"]) == 0
         assert int(gold[f"{c['name']}/controlnet_calls"]) == n_masked * fused
-        assert int(gold[f"{c['name']}/controlnet2_calls"]) == (2 * c["steps"] if c["flow"] == "iid_t2i" else 0)
+        assert int(gold[f"{c['name']}/controlnet2_calls"]) == (2 * c["steps"] if c["flow"].startswith("iid_t2i") else 0)
+        if f"{c['name']}/controlnet2_scales_seen" in gold.files:      # the one window on both nets (instantid_pipeline.py:566-578)
+            kw = mk.CN_VARIANTS[c["flow"]]
+            keep = [k_[0] for k_ in opipe.controlnet_keep(c["steps"], kw["control_guidance_start"], kw["control_guidance_end"], 1)]
+            assert np.array_equal(gold[f"{c['name']}/controlnet2_scales_seen"], np.array([mk.T2I_SCALE * k_ for k_ in keep] * 2))
+            assert np.array_equal(gold[f"{c['name']}/controlnet_scales_seen"], np.array([mk.IDN_SCALE * keep[i] for i in range(16, c["steps"]) for _ in range(n_masked)]))
+            assert 0.0 in keep[16:] and 1.0 in keep[16:]
     else:
         assert int(gold[f"{c['name']}/set_adapters_calls"]) == 2 * c["K"] + n_masked * fused
         assert int(gold[f"{c['name']}/controlnet_calls"]) == (2 * c["steps"] if c["flow"].startswith("lora_cn") else 0)      # called every step, also at keep = 0
