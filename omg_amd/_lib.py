@@ -176,6 +176,9 @@ def lib() -> C.CDLL:
     v = os.environ.get("OMG_ATTN_VARIANT")      # ditto for the attention kernels (bit 16: attn_fwd_kernel7 without its XCD-aware block order)
     if v:
         l.omg_debug_set_attn_variant(int(v, 0))
+    v = os.environ.get("OMG_MX8_SPLIT")         # ditto for the MX-fp8 GEMM: DMA split | debug bits << 8 (128 << 8: the one-tile-per-block form of the Linear kernel)
+    if v:
+        l.omg_debug_set_mx8_split(int(v, 0))
     _lib = l
     return l
 

@@ -284,6 +284,249 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_mx8_kernel_p (round 6) — the Linear form of the kernel above as a PERSISTENT tile walk with the next tile's stage 0
+// in flight under the current tile's last k-step and epilogue.  The MX-fp8 GEMM is the kernel furthest below its roofline and the only one that is not
+// power-capped: a K = 1280 tile is ten 128-wide stages — 9.3 us of matrix pipe at 2.2 GHz — inside ~18 us, the rest being the latency of its first stage
+// (2 - 3 us), its epilogue (4 - 5 us) and the dispatch gap.  gemm_kernel_v12 (gemm_v12.h) showed on the 16-bit kernel that loads issued IN FRONT of the
+// epilogue's stores do not queue behind them; the same move here, on the two-stage K loop as it is (the five-buffer ring does not fit beside 2 KB of scale
+// images per stage, and the loop is not what this kernel lacks):
+//   * grid = the CU count (a multiple of 8, so that a block's tiles stay on one XCD's share of the XCD-aware order); block b walks tiles b, b + grid, ...;
+//   * behind the barrier of a tile's LAST stage every wave has finished reading that stage's buffer: the 16 operand DMAs + the scale DMA of the NEXT
+//     tile's stage 0 go into it, one per MFMA slot of the last k-step — the slots that carry stage kt + 2's DMAs in the steady state and are empty there.
+//     The epilogue's XE staging region is the OTHER buffer, as before; the next tile therefore starts in the buffer its predecessor finished in, and a
+//     parity bit swaps the roles of the two buffers from tile to tile;
+//   * the next tile's coordinates are decoded at the TOP of a tile (while stage 0 is still landing) and held in SGPRs through the K loop; its descriptors
+//     and the lane's source offsets are written — unconditionally (gemm_v12.h's lesson: a conditional write keeps the old value alive round the loop) —
+//     after the current tile's last DMA has been issued; the epilogue works from its own copies of the tile's coordinates and from a lane id taken
+//     afresh from the exec-mask count, so that LICM cannot hoist its ~50 lane constants in front of the tile loop.
+// Same loads, same MFMA order per accumulator, same epilogue code: bitwise identical to the one-tile-per-block form (tests/test_mx8_gpu.py forces both).
+struct MxTile { int m0, n0, m_end, grp; };
+OMG_DEV MxTile mx_decode_tile(const GemmP& p, int vb, int ntiles) {
+  int bid = vb;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tiles_per_group = p.tiles_m * p.tiles_n;
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  const int per_group = 8 * p.tiles_n;
+  const int gid = t_in / per_group;
+  const int first_m = gid * 8;
+  const int gsz = (p.tiles_m - first_m) < 8 ? (p.tiles_m - first_m) : 8;
+  const int r = t_in - gid * per_group;
+  const int tm = first_m + (r % gsz);
+  const int tn = r / gsz;
+  const int m_base = (p.tile_groups > 1) ? grp * p.rows_per_group : 0;
+  MxTile t;
+  t.m_end = (p.tile_groups > 1) ? m_base + p.rows_per_group : p.M;
+  t.m0 = m_base + tm * 256;
+  t.n0 = tn * 256;
+  t.grp = grp;
+  return t;
+}
+// the first virtual block id >= vb (in steps of `step`) whose tile is computed (weight slot >= 0), or >= ntiles
+OMG_DEV int mx_next_tile(const GemmP& p, int vb, int step, int ntiles) {
+  if (p.w_adapter_stride == 0 || p.group_adapter == nullptr) return vb;
+  while (vb < ntiles) {
+    const MxTile t = mx_decode_tile(p, vb, ntiles);
+    if (p.group_adapter[t.grp] >= 0) break;
+    vb += step;
+  }
+  return vb;
+}
+OMG_DEV int mx_fresh_lane() {
+  int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(l));
+  return l;
+}
+
+template <typename T, int D1>
+__global__ __launch_bounds__(256, 1) void gemm_mx8_kernel_p(GemmP p) {
+  constexpr int MT = 4, NT = 4;
+  constexpr bool XE = true;
+  constexpr int EF = 0;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int l31 = lane & 31;
+  const int ntiles = p.tile_groups * p.tiles_m * p.tiles_n;
+  const int step = (int)gridDim.x;
+  const int nk = p.K / MXK;
+  int vb = mx_next_tile(p, (int)blockIdx.x, step, ntiles);
+  if (vb >= ntiles) return;
+
+  const long a_bytes = (long)(p.M - 1) * p.lda + p.K;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
+  const long w_bytes = (long)(p.N - 1) * p.ldw + p.K;
+  __amdgpu_buffer_rsrc_t rsW, rsS;
+  const bool sA = w == 0;               // wave 0 stages the A scales, wave 1 the W scales (1 KiB each per stage)
+  const bool sc_wave = w < 2;
+  const int s_step = (sA ? p.sa_ld : p.sw_ld) * 4;
+  const int ldoS = MX_SC + (sA ? 0 : 1024);
+  const int prow = lane >> 3, ppos = lane & 7;
+  const int dchunk = (ppos ^ ((w & 1) * 4 + (prow >> 1))) * 16;
+  const int stepA = (int)(32 * p.lda), stepW = (int)(32 * p.ldw);
+  const int ldo = w * 1024;
+  int m0, n0, m_end;
+  int voffA0, voffW0, voffS;
+  // the tile at (m0_, n0_) of weight-slot group grp_: descriptors and the lane's source offsets
+#define MXP_TILE(m0_, n0_, mend_, grp_)                                                                    \
+  do {                                                                                                     \
+    m0 = (m0_); n0 = (n0_); m_end = (mend_);                                                               \
+    int adapter_ = 0;                                                                                      \
+    if (p.group_adapter != nullptr) adapter_ = p.group_adapter[grp_];                                      \
+    const char* Wp_ = p.W + (p.w_adapter_stride != 0 ? (long)adapter_ * p.w_adapter_stride : 0);           \
+    const char* SWp_ = p.SW + (p.w_adapter_stride != 0 ? (long)adapter_ * p.sw_adapter_stride * 4 : 0);    \
+    rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp_, 0, (int)w_bytes, 0x00020000);                      \
+    const long s_shift_ = (!sA && p.w_adapter_stride != 0) ? (long)adapter_ * p.sw_adapter_stride * 4 : 0; \
+    rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(sA ? p.SA : SWp_), 0, (int)((long)nk * (sA ? p.sa_ld : p.sw_ld) * 4 - s_shift_), 0x00020000); \
+    const int s_rows_ = sA ? p.sa_ld : (p.w_adapter_stride != 0 ? (p.N + 3) & ~3 : p.sw_ld);              \
+    const int s_row0_ = (sA ? m0 : n0) + lane * 4;                                                         \
+    voffS = s_row0_ + 3 < s_rows_ ? s_row0_ * 4 : 0x7ffffff0;                                              \
+    voffA0 = (int)((long)(m0 + w * 8 + prow) * p.lda) + dchunk;                                            \
+    voffW0 = (int)((long)(n0 + w * 8 + prow) * p.ldw) + dchunk;                                            \
+  } while (0)
+  {
+    const MxTile t = mx_decode_tile(p, vb, ntiles);
+    MXP_TILE(t.m0, t.n0, t.m_end, t.grp);
+  }
+
+  const int wm = w >> 1, wn = w & 1;
+  const int sw = (l31 >> 1) & 7;
+  int foff[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) foff[ks][h] = l31 * 128 + (((ks * 4 + h * 2 + hi) ^ sw) << 4);
+  const int aB = wm * (128 * 128), bB = MX_TILE + wn * (128 * 128);
+  const int sAoff = MX_SC + (wm * 128 + l31) * 4, sWoff = MX_SC + 1024 + (wn * 128 + l31) * 4;
+  const int sshift = hi * 8;
+
+  int koff = 0, kst = 0;
+#define MX_PREP(kt_) do { koff = (kt_) * MXK; kst = (kt_); } while (0)
+#define MX_DMA(d_, nb_)                                                                                    \
+  do {                                                                                                     \
+    if ((d_) < 8) dma16(rsA, (nb_) + ldo + ((d_) & 7) * 4096, voffA0, koff + ((d_) & 7) * stepA);          \
+    else dma16(rsW, (nb_) + MX_TILE + ldo + ((d_) & 7) * 4096, voffW0, koff + ((d_) & 7) * stepW);         \
+  } while (0)
+#define MX_DMAS(nb_) do { if (sc_wave) dma16(rsS, (nb_) + ldoS, voffS, kst * s_step); } while (0)
+  i32x8 af[2][MT], bf[2][NT];
+  int sa[MT], sb[NT];
+  int san[MT], sbn[NT];
+#define MX_RD1(f_, sb_, ks_, r_)                                                                           \
+  do {                                                                                                     \
+    const bool isA_ = (r_) >= NT;                                                                          \
+    const int idx_ = isA_ ? (r_) - NT : (r_);                                                              \
+    const char* q_ = (sb_) + (isA_ ? aB : bB) + idx_ * 4096;                                               \
+    const u32x4 lo_ = *(const u32x4*)(q_ + foff[ks_][0]);                                                  \
+    const u32x4 hi_ = *(const u32x4*)(q_ + foff[ks_][1]);                                                  \
+    const i32x8 v_ = {(int)lo_[0], (int)lo_[1], (int)lo_[2], (int)lo_[3], (int)hi_[0], (int)hi_[1], (int)hi_[2], (int)hi_[3]}; \
+    if (isA_) af[f_][idx_] = v_; else bf[f_][idx_] = v_;                                                   \
+  } while (0)
+#define MX_RDS(da_, db__, sb_)                                                                             \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) da_[i] = (int)(*(const unsigned*)((sb_) + sAoff + i * 128) >> sshift); \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) db__[j] = (int)(*(const unsigned*)((sb_) + sWoff + j * 128) >> sshift); \
+  } while (0)
+#define MX_MM1(f_, ks_, n_)                                                                                \
+  acc[(n_) >> 2][(n_) & 3] = mfma_mx8(bf[f_][(n_) & 3], af[f_][(n_) >> 2], acc[(n_) >> 2][(n_) & 3], sb[(n_) & 3], sa[(n_) >> 2], ks_)
+#define MX_KSTEP(f_, ks_, RD_, rb_, rks_, RDS_, DMA_, d0_, dn_, db_, DSC_)                                 \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int n_ = 0; n_ < 16; ++n_) {                                                    \
+      MX_MM1(f_, ks_, n_);                                                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if ((RD_) && n_ < 8) MX_RD1(1 - (f_), rb_, rks_, n_);                                                \
+      if ((RDS_) && n_ == 8) MX_RDS(san, sbn, rb_);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if ((DMA_) && n_ < (dn_)) MX_DMA((d0_) + n_, db_);                                                   \
+      if ((DSC_) && n_ == 15) MX_DMAS(db_);                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }                                                                                                      \
+  } while (0)
+
+  // ---- the first tile's stage 0
+  int par = 0;                  // the stage buffer this tile's stage 0 lives in
+  MX_PREP(0);
+#pragma unroll
+  for (int d = 0; d < 16; ++d) MX_DMA(d, smem);
+  MX_DMAS(smem);
+  const bool gb_epi = p.group_bias != nullptr && !fold_group_bias(p);
+  for (;;) {
+    // the tile after this one: decoded here, while stage 0 is landing, and carried through the K loop in SGPRs
+    const int vbn = mx_next_tile(p, vb + step, step, ntiles);
+    const bool has_next = vbn < ntiles;
+    const MxTile tnx = mx_decode_tile(p, has_next ? vbn : vb, ntiles);
+    const int e_m0 = m0, e_n0 = n0, e_mend = m_end;
+    // the accumulators are DEFINED here, per tile (no loop-carried phi on 256 registers: with acc initialised at the loop's bottom hipcc shuffled it
+    // between the AGPR and the VGPR half and spilled it — 371 VGPRs, scratch traffic INSIDE the K loop); the bias loads' latency meets the wait for
+    // stage 0 below
+    f32x16 acc[MT][NT];
+    (void)acc_init_bias<T, MT, NT>(p, acc, mx_fresh_lane(), m0, n0 + wn * 128);
+    char* const b0 = smem + par * MX_STAGE;              // stages 0, 2, 4, ... of this tile
+    char* const b1 = smem + (par ^ 1) * MX_STAGE;        // stages 1, 3, 5, ...
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    MX_PREP(1);
+    if (nk > 1) {
+#pragma unroll
+      for (int d = 0; d < D1; ++d) MX_DMA(d, b1);
+      MX_DMAS(b1);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) MX_RD1(0, b0, 0, r);
+    MX_RDS(sa, sb, b0);
+
+#define MX_STAGE_BODY(HAS1_, HAS2_)                                                                        \
+    do {                                                                                                   \
+      const char* cur = (kt & 1) ? b1 : b0;                                                                \
+      char* nxt = (kt & 1) ? b0 : b1;                                                                      \
+      MX_KSTEP(0, 0, true, cur, 1, false, HAS1_, D1, 16 - D1, nxt, false);                                 \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+      __builtin_amdgcn_s_barrier();                                                                        \
+      if (HAS2_) MX_PREP(kt + 2);                                                                          \
+      MX_KSTEP(1, 1, HAS1_, nxt, 0, HAS1_, HAS2_, 0, D1, (char*)cur, HAS2_);                               \
+      if (HAS1_) {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) sa[i] = san[i];                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) sb[j] = sbn[j];                                     \
+      }                                                                                                    \
+    } while (0)
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) MX_STAGE_BODY(true, true);
+    if (kt < nk - 1) { MX_STAGE_BODY(true, false); ++kt; }
+    {   // the last stage: no load of this tile is left to issue
+      const char* cur = (kt & 1) ? b1 : b0;
+      MX_KSTEP(0, 0, true, cur, 1, false, false, 0, 0, (char*)cur, false);
+      // from here on the DMA state belongs to the NEXT tile (without one: this tile again, out of range, so that nothing is written conditionally)
+      MXP_TILE(tnx.m0, tnx.n0, tnx.m_end, tnx.grp);
+      if (!has_next) { voffA0 = 0x7ffffff0; voffW0 = 0x7ffffff0; voffS = 0x7ffffff0; }
+      MX_PREP(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                       // every wave has read the last of `cur`: it takes the next tile's stage 0
+      MX_KSTEP(1, 1, false, cur, 0, false, true, 0, 16, (char*)cur, true);
+    }
+#undef MX_STAGE_BODY
+    // XE staging region of the epilogue: the stage buffer the last stage did NOT use (released by that stage's barrier)
+    char* const xe = (((nk - 1) & 1) ? b0 : b1) + w * 8192;
+    const int lane_e = mx_fresh_lane();
+    epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane_e, e_m0 + wm * 128, e_n0 + wn * 128, e_mend, gb_epi, xe);
+    if (!has_next) break;
+    vb = vbn;
+    par ^= (nk - 1) & 1;                                  // the next tile's stage 0 sits in the buffer this tile's last stage used
+  }
+#undef MX_KSTEP
+#undef MX_MM1
+#undef MX_RDS
+#undef MX_RD1
+#undef MX_DMAS
+#undef MX_DMA
+#undef MX_PREP
+#undef MXP_TILE
+}
+
+// ------------------------------------------------------------------------------------------------
 // Quantiser: X[M, K] (fp16 / bf16, row stride ldx) -> Q[M, K] e4m3 bytes (row stride ldq) + S[K/128][s_ld] scale dwords.
 // Scale of a 32-block: the smallest power of two 2^e with amax / 2^e <= 448 (the e4m3 maximum), stored as E8M0 e + 127 —
 // no element saturates, the largest keeps all three mantissa bits.  A block of zeros gets byte 0 (2^-127).
@@ -330,6 +573,15 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const char* x, long ldx,
 }
 
 int g_mx_d1 = 12;      // measured best of 8 / 12 / 16 on the UNet's shapes (profiles/r02_mx8_bench.log)
+int mx_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
 int g_mx_dbg = 0;      // 64: register-direct epilogue instead of the transposed streaming one (tools / A-B only)
 
 template <typename T, bool CONV = false>
@@ -346,6 +598,18 @@ int launch_mx8(GemmP p, hipStream_t s, int mrows) {
     if (!attr) { attr = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel<T, D1_, CONV, XE_, EF_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); } \
     OMG_LAUNCH((gemm_mx8_kernel<T, D1_, CONV, XE_, EF_>), dim3(grid), dim3(256), lds, s, p);               \
   } while (0)
+  if constexpr (!CONV) {
+    // Linear problems: the persistent tile walk (gemm_mx8_kernel_p), unless a tool asks for the one-tile-per-block form (dbg bit 128) or another DMA split
+    if (!(g_mx_dbg & (64 | 128)) && g_mx_d1 >= 12 && g_mx_d1 < 16) {
+      static bool attr_p = false;
+      if (!attr_p) { attr_p = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel_p<T, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+      int cus = mx_num_cus() & ~7;
+      if (g_mx_dbg & 256) cus = 8;        // tests only: eight blocks, so that a small problem makes every block walk several tiles
+      const int pgrid = (grid > cus && cus > 0) ? cus : grid;
+      OMG_LAUNCH((gemm_mx8_kernel_p<T, 12>), dim3(pgrid), dim3(256), lds, s, p);
+      return omg_check_launch("gemm_mx8_p");
+    }
+  }
   if (g_mx_dbg & 64) MX_LAUNCH(12, false, 0);
   else if (g_mx_d1 >= 16) MX_LAUNCH(16, true, 0);
   else if (g_mx_d1 >= 12) MX_LAUNCH(12, true, 0);      // (one kernel per epilogue form, as gemm.hip does for v7, was measured 15-30 % SLOWER

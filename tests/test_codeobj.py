@@ -79,7 +79,19 @@ def test_no_scratch_access_between_the_first_and_the_last_mfma(family):
             continue                                       # form 0 of the XE tile: every form behind run-time tests, tools only
         mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
         assert mf, n
-        inside = [ins[i] for i in range(mf[0], mf[-1]) if ins[i].startswith("scratch_")]
+        if "gemm_mx8_kernel_p" in n:
+            # the persistent MX-fp8 kernel (round 6): the tile hand-over — next tile's coordinates, descriptors, accumulator initialisation — sits BETWEEN the
+            # stage bodies in address order and may touch its few spilled registers; what must stay clean is every stage body itself (a run of MFMAs
+            # less than 40 instructions apart)
+            runs, start = [], mf[0]
+            for a_, b_ in zip(mf, mf[1:] + [None]):
+                if b_ is None or b_ - a_ > 40:
+                    runs.append((start, a_))
+                    start = b_
+            assert len(runs) >= 3 and all(sum(1 for i in mf if r0 <= i <= r1) >= 16 for r0, r1 in runs), (n, runs)
+            inside = [ins[i] for r0, r1 in runs for i in range(r0, r1) if ins[i].startswith("scratch_")]
+        else:
+            inside = [ins[i] for i in range(mf[0], mf[-1]) if ins[i].startswith("scratch_")]
         assert not inside, (n, inside[:4])
 
 

@@ -93,6 +93,52 @@ def test_gemm_mx8_geglu_and_weight_slots(dev):
     torch.testing.assert_close(out.float().cpu(), ref, rtol=3e-3, atol=4e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,kind", [(2048, 1280, 1280, "res"), (1500, 520, 128, "bias"), (4096, 2560, 640, "geglu"), (3 * 1024, 1280, 256, "slots"),
+                                        (8192, 1024, 384, "silu")])
+def test_persistent_mx8_gemm_is_bitwise_the_one_tile_kernel(dev, dtype, M, N, K, kind):
+    """gemm_mx8_kernel_p (round 6: a persistent tile walk with the next tile's stage 0 issued under the current tile's last k-step; the two stage buffers
+    swap roles from tile to tile when the stage count is even) runs the loads, the MFMA order and the epilogue of the one-tile-per-block kernel: every
+    epilogue form, one / three / ten stages per tile (K = 128 / 384 / 1280: odd and even counts, i.e. with and without the buffer swap), ragged M and N,
+    per-sample weight slots with a skipped group — with one block per tile, with the CU count, and with EIGHT blocks so that every block walks many tiles."""
+    lib = L.lib()
+    a = gen((M, K), 21, dtype=dtype)
+    ta = ops.quant_mx8(a.to(dev))
+    kw = {}
+    if kind == "slots":
+        w = gen((3, N, K), 22, scale=K ** -0.5, dtype=dtype)
+        tw = ops.quant_mx8(w.reshape(3 * N, K).to(dev))
+        kw = dict(groups=3, w_group_adapter=torch.tensor([2, -1, 0], dtype=torch.int32, device=dev), n_per_adapter=N, bias=gen((N,), 23, dtype=dtype).to(dev))
+    else:
+        w = gen((N, K), 22, scale=K ** -0.5, dtype=dtype)
+        bias = gen((N,), 23, dtype=dtype).to(dev)
+        if kind == "geglu":
+            perm = ops.geglu_row_perm(N)
+            tw = ops.quant_mx8(w[perm].contiguous().to(dev))
+            kw = dict(bias=bias[perm.to(dev)].contiguous(), act=L.ACT_GEGLU)
+        else:
+            tw = ops.quant_mx8(w.to(dev))
+            kw = dict(bias=bias)
+            if kind == "res":
+                kw.update(residual=gen((M, N), 24, dtype=dtype).to(dev), out_scale=0.5)
+            if kind == "silu":
+                kw.update(act=L.ACT_SILU)
+    outs = {}
+    try:
+        for name, word in (("one_tile", 12 | (128 << 8)), ("persistent", 12), ("eight_blocks", 12 | (256 << 8))):
+            lib.omg_debug_set_mx8_split(word)
+            o = torch.full((M, N // 2 if kind == "geglu" else N), float("nan"), dtype=dtype, device=dev)
+            ops.gemm_mx8(ta, tw, out=o, out_dtype=dtype, **kw)
+            outs[name] = o
+    finally:
+        lib.omg_debug_set_mx8_split(12)
+    if kind == "slots":      # the skipped group's rows are never written by either form
+        assert torch.isnan(outs["one_tile"][1024:2048]).all() and torch.isnan(outs["persistent"][1024:2048]).all()
+        outs = {k_: torch.cat([v[:1024], v[2048:]]) for k_, v in outs.items()}
+    assert torch.isfinite(outs["one_tile"]).all()
+    assert torch.equal(outs["persistent"], outs["one_tile"]) and torch.equal(outs["eight_blocks"], outs["one_tile"])
+
+
 def test_gemm_mx8_at_bench_size_on_sampled_rows(dev):
     """(65536, 10240, 1280) with 64 weight-slot groups and GEGLU, (65536, 1280, 5120) with residual: sampled rows vs CPU fp32."""
     for (M, N, K, act) in [(65536, 10240, 1280, "geglu"), (65536, 1280, 5120, "none")]:
