@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel(GemmP p) {
 //   * grid = the CU count (a multiple of 8, so that a block's tiles stay on one XCD's share of the XCD-aware order); block b walks tiles b, b + grid, ...;
 //   * behind the barrier of a tile's LAST stage every wave has finished reading that stage's buffer: the 16 operand DMAs + the scale DMA of the NEXT
 //     tile's stage 0 go into it, one per MFMA slot of the last k-step — the slots that carry stage kt + 2's DMAs in the steady state and are empty there.
-//     The epilogue's XE staging region is the OTHER buffer, as before; the next tile therefore starts in the buffer its predecessor finished in, and a
-//     parity bit swaps the roles of the two buffers from tile to tile;
+//     They always go into buffer 0 and the epilogue's XE staging region is always buffer 1's operand area (both free behind that barrier whatever the
+//     stage count), so the buffers keep their roles from tile to tile and the K loop its immediate LDS offsets;
 //   * the next tile's coordinates are decoded at the TOP of a tile (while stage 0 is still landing) and held in SGPRs through the K loop; its descriptors
 //     and the lane's source offsets are written — unconditionally (gemm_v12.h's lesson: a conditional write keeps the old value alive round the loop) —
 //     after the current tile's last DMA has been issued; the epilogue works from its own copies of the tile's coordinates and from a lane id taken
@@ -447,8 +447,10 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel_p(GemmP p) {
     }                                                                                                      \
   } while (0)
 
-  // ---- the first tile's stage 0
-  int par = 0;                  // the stage buffer this tile's stage 0 lives in
+  // ---- the first tile's stage 0.  EVERY tile's stage 0 lives in buffer 0 (no parity: with run-time buffer roles the fragment reads lose their
+  // immediate offsets — the first version of this kernel swapped the buffers from tile to tile and its K loop ran 9 % slower at 8192^3).  Buffer 0 is free
+  // behind the last stage's barrier whatever the stage count: an even count's last stage computes from buffer 1 (buffer 0 was released a stage earlier), an
+  // odd count's from buffer 0 itself (released by this barrier).  The epilogue's XE staging region is buffer 1's operand area, equally free there.
   MX_PREP(0);
 #pragma unroll
   for (int d = 0; d < 16; ++d) MX_DMA(d, smem);
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel_p(GemmP p) {
     // stage 0 below
     f32x16 acc[MT][NT];
     (void)acc_init_bias<T, MT, NT>(p, acc, mx_fresh_lane(), m0, n0 + wn * 128);
-    char* const b0 = smem + par * MX_STAGE;              // stages 0, 2, 4, ... of this tile
-    char* const b1 = smem + (par ^ 1) * MX_STAGE;        // stages 1, 3, 5, ...
+    char* const b0 = smem;                               // stages 0, 2, 4, ... of every tile
+    char* const b1 = smem + MX_STAGE;                    // stages 1, 3, 5, ...
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     MX_PREP(1);
@@ -481,8 +483,8 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel_p(GemmP p) {
 
 #define MX_STAGE_BODY(HAS1_, HAS2_)                                                                        \
     do {                                                                                                   \
-      const char* cur = (kt & 1) ? b1 : b0;                                                                \
-      char* nxt = (kt & 1) ? b0 : b1;                                                                      \
+      const char* cur = smem + (kt & 1) * MX_STAGE;                                                        \
+      char* nxt = smem + ((kt + 1) & 1) * MX_STAGE;                                                        \
       MX_KSTEP(0, 0, true, cur, 1, false, HAS1_, D1, 16 - D1, nxt, false);                                 \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
       __builtin_amdgcn_s_barrier();                                                                        \
@@ -497,24 +499,23 @@ __global__ __launch_bounds__(256, 1) void gemm_mx8_kernel_p(GemmP p) {
     for (; kt < nk - 2; ++kt) MX_STAGE_BODY(true, true);
     if (kt < nk - 1) { MX_STAGE_BODY(true, false); ++kt; }
     {   // the last stage: no load of this tile is left to issue
-      const char* cur = (kt & 1) ? b1 : b0;
+      const char* cur = smem + (kt & 1) * MX_STAGE;
       MX_KSTEP(0, 0, true, cur, 1, false, false, 0, 0, (char*)cur, false);
       // from here on the DMA state belongs to the NEXT tile (without one: this tile again, out of range, so that nothing is written conditionally)
       MXP_TILE(tnx.m0, tnx.n0, tnx.m_end, tnx.grp);
       if (!has_next) { voffA0 = 0x7ffffff0; voffW0 = 0x7ffffff0; voffS = 0x7ffffff0; }
       MX_PREP(0);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                       // every wave has read the last of `cur`: it takes the next tile's stage 0
-      MX_KSTEP(1, 1, false, cur, 0, false, true, 0, 16, (char*)cur, true);
+      __builtin_amdgcn_s_barrier();                       // no wave reads a stage buffer any more: buffer 0 takes the next tile's stage 0
+      MX_KSTEP(1, 1, false, cur, 0, false, true, 0, 16, b0, true);
     }
 #undef MX_STAGE_BODY
-    // XE staging region of the epilogue: the stage buffer the last stage did NOT use (released by that stage's barrier)
-    char* const xe = (((nk - 1) & 1) ? b0 : b1) + w * 8192;
+    // XE staging region of the epilogue: buffer 1's operand area
+    char* const xe = b1 + w * 8192;
     const int lane_e = mx_fresh_lane();
     epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane_e, e_m0 + wm * 128, e_n0 + wn * 128, e_mend, gb_epi, xe);
     if (!has_next) break;
     vb = vbn;
-    par ^= (nk - 1) & 1;                                  // the next tile's stage 0 sits in the buffer this tile's last stage used
   }
 #undef MX_KSTEP
 #undef MX_MM1
