@@ -600,8 +600,15 @@ int launch_mx8(GemmP p, hipStream_t s, int mrows) {
     OMG_LAUNCH((gemm_mx8_kernel<T, D1_, CONV, XE_, EF_>), dim3(grid), dim3(256), lds, s, p);               \
   } while (0)
   if constexpr (!CONV) {
-    // Linear problems: the persistent tile walk (gemm_mx8_kernel_p), unless a tool asks for the one-tile-per-block form (dbg bit 128) or another DMA split
-    if (!(g_mx_dbg & (64 | 128)) && g_mx_d1 >= 12 && g_mx_d1 < 16) {
+    // Linear problems with FEW column tiles and a SHORT K loop (N <= 1280, K <= 1280: the attention projections — 11 % of the fp8 step) run the persistent
+    // tile walk gemm_mx8_kernel_p; everything else keeps one tile per block.  Measured in situ, twice, interleaved on one box
+    // (profiles/r06_by_shape_fp8_{one_tile,persistent}*.txt): 65536 x 1280 x 1280 1228 -> 1340 and 1267 -> 1374 TF/s (+ 8 ... 9 %), 262144 x 640 x 640 667 -> 771 and
+    // 685 -> 804 (+ 16 ... 17 %), 32768 x 1280 x 1280 + 1 ... 2 %; but GEGLU 65536 x 10240 x 1280 - 8 ... 10 %, x 3840 x 1280 - 2 ... 5 %, K = 5120 - 3 %, 8192^3 - 8 %: with many
+    // column tiles / long K the hand-over's vmcnt(0) in front of the next tile's first barrier waits for the previous epilogue's stores to drain (CDNA4's
+    // vmcnt counts stores), which a FRESH workgroup overlaps with its prologue — at fp8 rates a tile is half as long as the 16-bit kernel's and the same
+    // store volume weighs twice.  Tools: dbg bit 128 = one tile per block everywhere, bit 512 = the walk everywhere.
+    const bool small = p.tiles_n <= 5 && p.K <= 1280 && p.act != OMG_ACT_GEGLU;
+    if (!(g_mx_dbg & (64 | 128)) && g_mx_d1 >= 12 && g_mx_d1 < 16 && (small || (g_mx_dbg & 512))) {
       static bool attr_p = false;
       if (!attr_p) { attr_p = true; (void)hipFuncSetAttribute((const void*)gemm_mx8_kernel_p<T, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
       int cus = mx_num_cus() & ~7;

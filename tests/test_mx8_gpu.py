@@ -125,7 +125,7 @@ def test_persistent_mx8_gemm_is_bitwise_the_one_tile_kernel(dev, dtype, M, N, K,
                 kw.update(act=L.ACT_SILU)
     outs = {}
     try:
-        for name, word in (("one_tile", 12 | (128 << 8)), ("persistent", 12), ("eight_blocks", 12 | (256 << 8))):
+        for name, word in (("one_tile", 12 | (128 << 8)), ("persistent", 12 | (512 << 8)), ("eight_blocks", 12 | ((256 | 512) << 8))):      # 512: the walk whatever the shape
             lib.omg_debug_set_mx8_split(word)
             o = torch.full((M, N // 2 if kind == "geglu" else N), float("nan"), dtype=dtype, device=dev)
             ops.gemm_mx8(ta, tw, out=o, out_dtype=dtype, **kw)

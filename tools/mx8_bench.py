@@ -25,7 +25,7 @@ def main():
     shapes = [(1024, 10240, 1280, "32^2 geglu"), (1024, 1280, 5120, "32^2 ffout"), (1024, 3840, 1280, "32^2 qkv"), (1024, 1280, 1280, "32^2 proj"),
               (4096, 5120, 640, "64^2 geglu"), (4096, 640, 2560, "64^2 ffout"), (4096, 1920, 640, "64^2 qkv"), (4096, 640, 640, "64^2 proj")]
     print("# shape: fp16 TF/s | mx8 TF/s: one tile per block at DMA split 8 / 12 / 16, 12 with the register-direct epilogue, and (round 6) the PERSISTENT "
-          "tile walk (gemm_mx8_kernel_p, the default) | quantiser us (GB/s)")
+          "tile walk (gemm_mx8_kernel_p; the launcher picks it for N <= 1280, K <= 1280) | quantiser us (GB/s)")
     for hw, N, K, tag in shapes + [(8192 // B if B <= 8192 else 1, 8192, 8192, "8192^3")]:
         M = B * hw
         x = torch.randn(M, K, device=dev, dtype=dt)
@@ -37,7 +37,7 @@ def main():
         t16 = timeit(lambda: ops.gemm(x, w, out=out, act=act))
         xq, wq = ops.quant_mx8(x), ops.quant_mx8(w)
         row = []
-        for d1 in (8 | (128 << 8), 12 | (128 << 8), 16, 12 | (64 << 8), 12):      # dbg bit 128 = the one-tile form at split 12 (8: never persistent)
+        for d1 in (8 | (128 << 8), 12 | (128 << 8), 16, 12 | (64 << 8), 12 | (512 << 8)):      # dbg bit 128 = one tile per block, 512 = the persistent walk, whatever the shape
             lib.omg_debug_set_mx8_split(d1)
             row.append(fl / timeit(lambda: ops.gemm_mx8(xq, wq, out=out, act=act)) / 1e9)
         lib.omg_debug_set_mx8_split(12)
