@@ -199,7 +199,7 @@ typedef struct {
   const void* Q; int64_t ldq; int64_t q_bstride;   /* row stride / batch stride (elements) */
   const void* K; int64_t ldk; int64_t k_bstride;
   const void* Vt;             /* [B, heads, 64, Nkv_pad] from omg_transpose_v (its key order); columns >= Nkv MUST be zero (it writes
-                                 them so): attn_fwd_kernel3 masks no score, the padded keys cancel against those zeros.  May be
+                                 them so): the kernels that read it mask no score, the padded keys cancel against those zeros.  May be
                                  NULL when V (below) is given and Nkv > 128 */
   int32_t Nkv_pad;            /* % 64 == 0                                            */
   const int32_t* qk_src;      /* device [B]: batch index supplying Q,K; NULL = identity */

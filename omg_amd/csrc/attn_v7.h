@@ -1,8 +1,8 @@
 // attn_v7.h — the self-attention kernel of the product (more than 128 keys, V given ROW-MAJOR in omg_attn_args.V).  Written in round 4, first run
-// and landed in round 5 (profiles/r05_exp_attn_v7_*.log: torch.equal with attn_fwd_kernel3 on whole and ragged tiles, plain / borrowed Q,K /
-// accumulate; with omg_transpose_v gone from the self-attention path the benchmark step is 0.5 - 1 % shorter).
+// and landed in round 5 (profiles/r05_exp_attn_v7_*.log: torch.equal with attn_fwd_kernel3 — round 3's kernel on a V^T image, deleted in round 6 — on
+// whole and ragged tiles, plain / borrowed Q,K / accumulate; with omg_transpose_v gone from the self-attention path the benchmark step is 0.5 - 1 % shorter).
 //
-// attn_fwd_kernel7 = attn_fwd_kernel3 (attn.hip: 64 query rows per wave, K / V tiles by LDS-DMA, swapped S^T = K Q^T, O^T = V^T P^T) reading V
+// attn_fwd_kernel7 = the structure described in attn.hip (64 query rows per wave, K / V tiles by LDS-DMA, swapped S^T = K Q^T, O^T = V^T P^T) reading V
 // ROW-MAJOR — [key][d], exactly as the QKV projection wrote it — instead of the K-major V^T image omg_transpose_v makes once per attention call
 // (0.9 % of the benchmark step: 3648 launches of 51 us).  The V tile is staged like the K tile (same LDS-DMA pattern, same XOR swizzle) and the
 // P.V MFMA's A operand — 32 d x 16 keys, eight keys per lane — comes out of it by two `ds_read_b64_tr_b16` (gfx950's transposing LDS read) per
@@ -13,8 +13,7 @@
 // part before the kernel is trusted): per group of 16 lanes, lane i supplies the address of 4 consecutive 16-bit elements = row (i >> 2),
 // columns 4 (i & 3) .. + 3 of a 4 x 16 block, and lane c receives column c (4 elements, row order).
 // Ragged last tile: the staged rows past Nkv repeat the last key (as K's do) — finite values, so the probabilities of those keys are set to
-// zero where v3 relied on zero columns of V^T; the ones fragment of the denominator is masked as in v3.  Everything else — loads, MFMA order,
-// softmax arithmetic, stores — is v3's: the result is torch.equal with it (tests/test_kernels_gpu.py).
+// zero (a V^T image has zero columns there instead); with them zero the denominator (below) needs no mask either.
 // Two questions rode on the same kernel in round 5 (profiles/r05_exp_attn_v7_stagger.log, _xcd.log):
 //   * do the two workgroups of a CU run in lockstep, and does de-phasing them (half of the first-round workgroups started 10 / 20 / 40 us late)
 //     recover what the 32 x 32 launches lose against the 64 x 64 ones?  +5 ... 8 % at 32 x 32 in the microbenchmark, nothing at 64 x 64 — and
