@@ -248,15 +248,12 @@ OMG_DEV void xe_flush(const GemmP& p, const EpiCtx<4>& cx, int i, int col0) {
   asm volatile("" ::: "memory");
 }
 // SiLU / per-row group bias / residual decided at run time inside the unit loop: the rare combinations
-// RL — where the residual comes from: 0 register-direct loads one row block ahead; 1 the whole tile staged in LDS by LDS-DMA (res_stage_dma / gemm_v12.h's TAIL hooks);
-// 2 (round 6, gemm_kernel_v12 form 6) row blocks 0 and 1 staged in LDS, row blocks 2 and 3 by register-direct loads issued at the epilogue's start — both of their 16 loads
-// in flight under the arithmetic of row blocks 0 and 1 — so that the staged image is 64 KB instead of 128 and two LDS buffers stay free for the next tile's stage 0.
-template <typename T, int MT, int NT, bool RS, bool GENERIC, bool XE = false, int RL = 0>
+template <typename T, int MT, int NT, bool RS, bool GENERIC, bool XE = false, bool RL = false>
 OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<NT>& cx, bool has_gb) {
   const float osc = p.out_scale;
   const bool has_rs = GENERIC ? p.residual != nullptr : RS;
-  if constexpr (RL != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged residual rows have landed (own DMAs, own LDS slice)
-  u32x4 rraw[2][NT][2];         // residual of row block i: the lane's NT*2 16-byte units, fetched one row block ahead (RL == 2: row blocks 2 and 3)
+  if constexpr (RL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staged residual tile has landed (own DMAs, own LDS slice)
+  u32x4 rraw[2][NT][2];         // residual of row block i: the lane's NT*2 16-byte units, fetched one row block ahead
 #define OMG_FETCH_RES(i_, buf_)                                                                            \
   do {                                                                                                     \
     const int gm_ = cx.wm0 + (i_) * 32 + cx.l31;                                                           \
@@ -265,13 +262,12 @@ OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<N
       _Pragma("unroll") for (int pr = 0; pr < 2; ++pr)                                                     \
         rraw[buf_][j][pr] = __builtin_amdgcn_raw_buffer_load_b128(cx.rsR, ro_ | cx.voob[j][pr], (j * 32 + pr * 16) * 2, 0); \
   } while (0)
-  if (has_rs && RL == 0) OMG_FETCH_RES(0, 0);
-  if constexpr (RL == 2) { static_assert(MT == 4, "two staged + two register-direct row blocks"); OMG_FETCH_RES(2, 0); OMG_FETCH_RES(3, 1); }
+  if (has_rs && !RL) OMG_FETCH_RES(0, 0);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int gm = cx.wm0 + i * 32 + cx.l31;
     const bool row_ok = gm < cx.m_end;
-    if (has_rs && RL == 0 && i + 1 < MT) OMG_FETCH_RES(i + 1, (i + 1) & 1);
+    if (has_rs && !RL && i + 1 < MT) OMG_FETCH_RES(i + 1, (i + 1) & 1);
     const int ro = row_ok ? gm * (int)p.ldc * 2 + cx.lane_col : EPI_OOB;
     const int go = GENERIC && has_gb && row_ok ? ((gm / p.rows_per_group) * (int)p.ldgb) * 2 + cx.lane_col : EPI_OOB;
 #pragma unroll
@@ -295,9 +291,8 @@ OMG_DEV void epilogue_rows(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<N
         }
         if (has_rs) {
           // RL: the lane's 16 bytes (8 columns) of row l31 from the LDS image res_stage_dma wrote: 16-byte piece c of row r at position c ^ (r & 15)
-          const bool staged = RL == 1 || (RL == 2 && i < 2);
-          const u32x4 rr = staged ? *(const u32x4*)(cx.rl + i * 8192 + cx.l31 * 256 + (((4 * j + 2 * pr + cx.hi) ^ (cx.l31 & 15)) << 4))
-                                  : rraw[RL == 2 ? i - 2 : i & 1][j][pr];
+          const u32x4 rr = RL ? *(const u32x4*)(cx.rl + i * 8192 + cx.l31 * 256 + (((4 * j + 2 * pr + cx.hi) ^ (cx.l31 & 15)) << 4))
+                              : rraw[i & 1][j][pr];
           unsigned q[4] = {rr[0], rr[1], rr[2], rr[3]};
           swap_runs<T>(q);
           u32x4 sw = {q[0], q[1], q[2], q[3]};
@@ -353,7 +348,7 @@ OMG_DEV void epilogue_geglu(const GemmP& p, f32x16 (&acc)[MT][NT], const EpiCtx<
 
 // EF = the ONE epilogue form compiled into the kernel: 0 = all of them behind run-time branches (small tiles, v6); 1 = bias only,
 // 2 = + residual staged in LDS (res_stage_dma), 3 = GEGLU, 4 = per-row group bias / SiLU / residual decided per unit at run time,
-// 5 = + residual by register-direct loads (kernels without a free LDS slice for the staging), 6 = + residual half staged, half register-direct (RL == 2 above).
+// 5 = + residual by register-direct loads (kernels without a free LDS slice for the staging).
 // One form per kernel: with all forms behind run-time branches the 256-accumulator kernels spill inside the epilogue, and a scratch reload
 // there waits on vmcnt — i.e. on every store in flight (the 20 % residual penalty of round 2 was mostly that).
 template <typename T, int MT, int NT, bool XE = false, int EF = 0>
@@ -385,8 +380,6 @@ OMG_DEV void epilogue_direct(const GemmP& p, f32x16 (&acc)[MT][NT], int lane, in
     epilogue_rows<T, MT, NT, false, true, XE>(p, acc, cx, has_gb);
   } else if constexpr (EF == 5) {
     epilogue_rows<T, MT, NT, true, false, XE>(p, acc, cx, false);
-  } else if constexpr (EF == 6) {
-    epilogue_rows<T, MT, NT, true, false, XE, 2>(p, acc, cx, false);
   } else {
     if (geglu) {
       epilogue_geglu<T, MT, NT, XE>(p, acc, cx, ((wn0 >> 1) + cx.hi * 8) * 2);   // GEGLU output is half as wide

@@ -123,13 +123,9 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
   constexpr int STAGE_BYTES = (BM_ + BN_) * BKc * 2;
   constexpr int HALF = 32768;
   static_assert(A_BYTES == HALF && STAGE_BYTES == 2 * HALF, "the ring's canonical roles are the two-stage layout");
-  constexpr bool EARLY_RES = EF == 2 || EF == 6;      // residual rows in flight behind the last stage's barrier
-  constexpr bool HALF_RES = EF == 6;       // round 6: only row blocks 0, 1 of the residual are staged (64 KB: buffers 2, 3), row blocks 2, 3 come by register-direct loads
-  constexpr bool PERSIST = EF != 2;        // tile walk + the next tile's first stage(s) issued in the same window (form 2: one tile per block, header)
+  constexpr bool EARLY_RES = EF == 2;      // the residual tile in flight behind the last stage's barrier; one tile per block (header)
+  constexpr bool PERSIST = EF != 2;        // tile walk + the next tile's stages 0 and 1 issued in the same window
   constexpr bool PREFETCH = PERSIST;
-  constexpr bool PREFETCH2 = PERSIST && !HALF_RES;      // stage 1 as well — not beside a residual image (form 6: buffers 2, 3 hold it until the epilogue has read it)
-  constexpr int RES_SLOTS = HALF_RES ? 16 : 32;         // TAIL slots that carry residual DMAs
-  constexpr int PF0 = HALF_RES ? 16 : 0;                // first TAIL slot of the next tile's stage 0
   static_assert(OMG_KS_LAST_TAILS >= 32, "32 prefetch DMAs / 32 residual DMAs");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -302,21 +298,21 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
   do {                                                                                                     \
     if constexpr (EARLY_RES) {                                                                             \
       if constexpr ((n_) == 0) lane_l = fresh_lane();                                /* the address arithmetic stays HERE: computed from `lane` */ \
-      if constexpr ((n_) < RES_SLOTS) {                                              /* it is loop-invariant and would sit in registers through the K loop */ \
+      if constexpr ((n_) < 32) {                                                     /* it is loop-invariant and would sit in registers through the K loop */ \
         constexpr int i_ = (n_) >> 3, u_ = (n_) & 7;                                                       \
         const int rr_ = u_ * 4 + (lane_l >> 4);                                                            \
         const int gm_ = e_m0 + wm * 128 + i_ * 32 + rr_;                                                   \
         const int col_ = e_n0 + wn * 128 + (((lane_l & 15) ^ (rr_ & 15)) << 3);                            \
         const int off_ = (gm_ < e_mend && col_ < p.N) ? (gm_ * (int)p.ldr + col_) * 2 : EPI_OOB;           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsRes, (lds_ptr_t)(smem + (HALF_RES ? 2 * HALF + w * 16384 : w * 32768) + i_ * 8192 + u_ * 1024), 16, off_, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsRes, (lds_ptr_t)(smem + w * 32768 + i_ * 8192 + u_ * 1024), 16, off_, 0, 0, 0); \
       }                                                                                                    \
     }                                                                                                      \
     if constexpr (PREFETCH) {                                                                              \
-      if constexpr ((n_) == PF0) OMG_PREP(0);                                                              \
-      if constexpr (PREFETCH2 && (n_) == AB + WB) OMG_PREP(1);                                             \
-      if constexpr ((n_) >= PF0 && (n_) < PF0 + AB + WB) {                                                 \
-        if (has_next) OMG_DMA((n_) >= PF0 && (n_) < PF0 + AB + WB ? (n_) - PF0 : 0, smem);                 \
-      } else if constexpr (PREFETCH2 && (n_) >= AB + WB && (n_) < 2 * (AB + WB)) {                         \
+      if constexpr ((n_) == 0) OMG_PREP(0);                                                                \
+      if constexpr ((n_) == AB + WB) OMG_PREP(1);                                                          \
+      if constexpr ((n_) < AB + WB) {                                                                      \
+        if (has_next) OMG_DMA((n_) < AB + WB ? (n_) : 0, smem);                                            \
+      } else if constexpr ((n_) < 2 * (AB + WB)) {                                                         \
         if (has_next && nk > 1) OMG_DMA((n_) >= AB + WB && (n_) < 2 * (AB + WB) ? (n_) - (AB + WB) : 0, smem + STAGE_BYTES); \
       }                                                                                                    \
     }                                                                                                      \
@@ -335,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
   for (;;) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (!PREFETCH2 || first) {      // stage 1: prefetched with stage 0 where two stages fit beside the epilogue's LDS (forms 1, 3, 4), else issued here
+    if (!PREFETCH || first) {
       OMG_PREP(1);
       if (nk > 1) OMG_DMAN(0, AB + WB, smem + STAGE_BYTES);
     }
@@ -359,9 +355,6 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_v12(GemmP p) {
       if constexpr (!EARLY_RES) res_stage_dma(p, smem + w * 32768, lane_e, e_m0 + wm * 128, e_n0 + wn * 128, e_mend);
       epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane_e, e_m0 + wm * (MT * 32), e_n0 + wn * (NT * 32), e_mend, gb_epi, smem + 2 * STAGE_BYTES + w * 8192,
                                          smem + w * 32768);
-    } else if constexpr (EF == 6) {      // the staged half of the residual: buffers 2, 3 (16 KB per wave); buffers 0, 1 already hold the next tile's stage 0
-      epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane_e, e_m0 + wm * (MT * 32), e_n0 + wn * (NT * 32), e_mend, gb_epi, smem + 2 * STAGE_BYTES + w * 8192,
-                                         smem + 2 * HALF + w * 16384);
     } else
     epilogue_direct<T, MT, NT, XE, EF>(p, acc, lane_e, e_m0 + wm * (MT * 32), e_n0 + wn * (NT * 32), e_mend, gb_epi, smem + 2 * STAGE_BYTES + w * 8192);
     if (!PERSIST || !has_next) break;
@@ -431,11 +424,6 @@ int launch_v12_form(const GemmP& p, hipStream_t s, int mrows) {
   if (gb_rows || p.act == OMG_ACT_SILU) return launch_v12<T, CONV, 4>(p, s, mrows);
   // (round 5, profiles/r05_res_form_ab_*.log: sending residual launches to the PERSISTENT generic form 4 — residual by register-direct loads —
   // instead of this one-tile-per-block LDS-staged form was 1 ... 4 % slower on seven of nine shapes: the staged residual wins over the tile walk)
-  if (p.residual != nullptr) {
-    // Linear: form 6 (persistent, half-staged residual); convolutions keep form 2 (the conv instance of form 6 spills 41 VGPRs: its tile hand-over also carries
-    // the 24 per-row-block pixel coordinates).  Tools: dbg bit 17 = form 2 everywhere.
-    if constexpr (!CONV) { if (!(g_dbg & 0x20000)) return launch_v12<T, CONV, 6>(p, s, mrows); }
-    return launch_v12<T, CONV, 2>(p, s, mrows);
-  }
+  if (p.residual != nullptr) return launch_v12<T, CONV, 2>(p, s, mrows);
   return launch_v12<T, CONV, 1>(p, s, mrows);
 }

@@ -39,10 +39,7 @@ def test_the_16_bit_gemm_instances_of_the_256_tile_use_no_scratch_at_all(ks):
         seen.setdefault(form, []).append(conv)
         assert k["agpr_count"] == 256 and k["max_flat_workgroup_size"] == 256, n        # 256 accumulators in AGPRs, one wave per SIMD
         # no scratch: the tile walk's scalar state may be parked in VGPR LANES (v_writelane / v_readlane, `sgpr_spill_count`), never in memory
-        if form == 6:      # round 6's persistent residual form (experiment): a handful of SCALARS overflow the lanes into scratch — written in the prologue, re-read at the epilogue's start
-            assert k["private_segment_fixed_size"] <= 32 and k["vgpr_spill_count"] <= 7, (n, k["private_segment_fixed_size"])
-        else:
-            assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (n, k["private_segment_fixed_size"])
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (n, k["private_segment_fixed_size"])
         assert k["group_segment_fixed_size"] == 0, n                                        # dynamic LDS only: 5 x 32 KB
     dev = not pick(ks, "gemm_kernel_v12", "IDF16b")                                     # make DEV=1: the f16 instances only
     assert all(f in seen and len(seen[f]) == (2 if dev else 4) for f in (1, 2, 3, 4)), seen      # f16 / bf16 x Linear / conv
@@ -62,8 +59,7 @@ def test_attention_kernels_fit_two_workgroups_per_cu_without_scratch(ks):
 
 def test_scratch_users_are_known_and_small(ks):
     """Whatever spills must be on this list with a bound — a new entry is a regression to look at, not to wave through."""
-    allowed = {"gemm_mx8_kernel": 128,       # bytes per lane: the MX-fp8 kernel's XE epilogue (4-26 VGPRs, DESIGN §5)
-               "gemm_kernel_v12": 32}        # form 6 only (checked by form in the test above): scalars that overflow the spill lanes
+    allowed = {"gemm_mx8_kernel": 128}       # bytes per lane: the MX-fp8 kernel's XE epilogue (4-26 VGPRs, DESIGN §5)
     for n, k in ks.items():
         sz = k["private_segment_fixed_size"]
         if sz:
