@@ -310,12 +310,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
   for (int t = 0; t < nfull; ++t) tile_body(t, std::false_type{});
   if (nfull < ntiles) tile_body(nfull, std::true_type{});
 
+  // Epilogue.  A lane owns, per 32-wide d block and group g, FOUR consecutive d of its query row (d = 32 dt + 8 g + 4 hi + 0..3): 8-byte stores, 16 per query
+  // block and lane, each instruction touching 32 rows x 2 pieces — the store-issue-bound tail the guide prices at ~9 k cycles per block (T21).  Round 6: the
+  // two lane halves of a row hold ADJACENT pieces, so one v_permlane32_swap per dword pairs the pieces of groups g and g + 1 — the low half ends up with all
+  // eight d of group g, the high half with those of g + 1 — and each lane stores 16 bytes: half the store instructions, whole 16-byte pieces.  Same values,
+  // same rounding (the swap moves the already packed 16-bit results).  The accumulate form (tools / tests only on this kernel) and outputs that are not
+  // 16-byte aligned keep the 8-byte stores.
+  const bool wide = !p.accumulate && (p.ldo & 7) == 0 && (p.o_bs & 7) == 0 && (((unsigned long long)p.O) & 15) == 0;
 #pragma unroll
   for (int qb = 0; qb < QW; ++qb) {
     const float l_tot = l_run[qb] + den16_read(den16[qb]);
     const float inv = p.out_scale / l_tot;
-    if (qrow[qb] < p.Nq) {
-      char* op = p.O + ((long)b * p.o_bs + (long)qrow[qb] * p.ldo + h * 64) * 2;
+    char* op = p.O + ((long)b * p.o_bs + (long)(qrow[qb] < p.Nq ? qrow[qb] : 0) * p.ldo + h * 64) * 2;
+    if (wide) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          unsigned x[2], y[2];                      // the lane's packed pieces of groups 2 g2 and 2 g2 + 1
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            V4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (T)(o[qb][dt][(2 * g2 + k) * 4 + e] * inv);
+            const u32x2 w2 = __builtin_bit_cast(u32x2, pk);
+            if (k == 0) { x[0] = w2[0]; x[1] = w2[1]; } else { y[0] = w2[0]; y[1] = w2[1]; }
+          }
+          // lanes 32..63 of x <-> lanes 0..31 of y: low half = [own x | partner's x] (d 8 g .. 8 g + 7), high half = [partner's y | own y] (g + 1)
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1" : "+v"(x[0]), "+v"(x[1]), "+v"(y[0]), "+v"(y[1]));
+          const u32x4 out = {x[0], x[1], y[0], y[1]};
+          if (qrow[qb] < p.Nq) *(u32x4*)(op + (dt * 32 + 16 * g2 + 8 * hi) * 2) = out;
+        }
+    } else if (qrow[qb] < p.Nq) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
