@@ -594,6 +594,8 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
   // (v6) and v2 want the V^T image: a caller that passes only V there gets an error, not a silent fallback.
   if (a->V != nullptr && (a->Nkv > 128 || a->Vt == nullptr)) {
     OMG_REQUIRE(g_attn_variant == 0 || g_attn_variant == 7, "omg_attn_fwd: the forced variant reads a V^T image, the caller passed row-major V (tools: pass Vt)");
+    // attn_fwd_kernel7 addresses a (sample, head) slice of K / V with 32-bit offsets behind a buffer descriptor
+    OMG_REQUIRE(((long)a->Nkv * a->ldk + 64) * 2 < 0x7fffffffL && ((long)a->Nkv * a->ldv + 64) * 2 < 0x7fffffffL, "omg_attn_fwd: a K / V slice beyond 2 GB");
     OMG_REQUIRE(a->ldv % 8 == 0 && a->v_bstride % 8 == 0, "omg_attn_fwd: V strides must be multiples of 8 elements");
     OMG_REQUIRE(a->Nkv > 128, "omg_attn_fwd: row-major V needs more than 128 keys (pass Vt from omg_transpose_v below that)");
     dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);

@@ -60,6 +60,11 @@ template <> struct MfmaInit<bf16> {
 // situ (whole benchmark step, same box, profiles/r06_bench_fp16_den{0,1}*.json) 0.4064 / 0.4056 -> 0.4100 / 0.4099 images/s, self-attention 898 -> 943 and
 // 754 -> 785 TF/s.  The other two forms are deleted.  Against the fp32 reference all three pass the same tolerance; this one differs from round 3's by the
 // summation order of the same rounded probabilities (<= 2 ulp of the 16-bit output, tests/test_kernels_gpu.py).
+// 16 bytes per lane, global -> LDS, through a buffer descriptor (non-template on purpose: see dma16 in gemm_epilogue.h)
+__device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t rs, char* lds, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (attn_lds_ptr_t)lds, 16, voff, soff, 0, 0);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* Vrm, long ldv, long v_bs, int xcd_order) {
   constexpr int QW = 2;                      // 32-row query blocks per wave
@@ -116,35 +121,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
         vtr[r][dt] = key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4) + (i16 & 1) * 8;
       }
   }
+  // Descriptor addressing (round 6): the (sample, head) slice of K / of V behind an SGPR descriptor, the lane's two row offsets as 32-bit VGPRs that never
+  // change, the tile as a SCALAR offset.  `global_load_lds` with 64-bit lane addresses costs the issuing wave ~30 cycles more of MFMA issue per piece than
+  // `buffer_load ... lds` (tools/ubench/mfma_f32_rate.hip: a burst of eight 133 -> 142 TF/s on the fp32 convolution's mix), and the four running 64-bit
+  // pointers of round 5 (one add each per tile) are gone from a loop that is bound by its VALU.  The launcher checks that a slice fits 31 bits.
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)(((long)(p.Nkv - 1) * p.ldk + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)(((long)(p.Nkv - 1) * ldv + 64) * 2), 0x00020000);
+  int kvo[2], vvo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    kvo[j] = srow[j] * p.ldk * 2 + schunk[j];
+    vvo[j] = srow[j] * (int)ldv * 2 + schunk[j];
+  }
+  const int kstep = KVB * p.ldk * 2, vstep = KVB * (int)ldv * 2;
+  // the ragged last tile: rows past the end repeat the last key (their scores are masked / their P is zeroed below)
   auto dma_tile = [&](int kv0, int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int key = kv0 + srow[j];
-      if (key > p.Nkv - 1) key = p.Nkv - 1;          // rows past the end repeat the last key; their scores are masked below
-      const char* ks_ = kbase + (long)key * p.ldk * 2 + schunk[j];
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)ks_, (attn_lds_ptr_t)(smem + buf * TILE + (w + 4 * j) * 1024), 16, 0, 0);
-      const char* vs_ = vbase + (long)key * ldv * 2 + schunk[j];      // the same 8 rows x 128 B pattern as K: rows past the end repeat the last key, their P is zeroed
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)vs_, (attn_lds_ptr_t)(smem + (2 + buf) * TILE + (w + 4 * j) * 1024), 16, 0, 0);
+      if (key > p.Nkv - 1) key = p.Nkv - 1;
+      attn_dma16(rsK, smem + buf * TILE + (w + 4 * j) * 1024, key * p.ldk * 2 + schunk[j], 0);
+      attn_dma16(rsV, smem + (2 + buf) * TILE + (w + 4 * j) * 1024, key * (int)ldv * 2 + schunk[j], 0);
     }
   };
-  // whole tiles: the lane's two K rows and two V rows advance by 64 keys per tile — running 64-bit pointers, one add each.  Recomputing
-  // `base + key * ld * 2` per tile (above, kept for the ragged last tile's clamp) was 8 v_mul_lo_u32 + 4 v_mad_u64_u32 per tile and wave: quarter-rate
-  // integer multiplies, ~15 % of the loop's VALU cycles in a kernel that is bound by them (round 5, found reading the emitted loop)
-  const char* kp[2];
-  const char* vp[2];
-  const long kstep = (long)KVB * p.ldk * 2, vstep = (long)KVB * ldv * 2;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    kp[j] = kbase + (long)srow[j] * p.ldk * 2 + schunk[j];
-    vp[j] = vbase + (long)srow[j] * ldv * 2 + schunk[j];
-  }
-  auto dma_whole = [&](int buf) {
+  // whole tile t: the same 8 rows x 128 B pattern for K and for V
+  auto dma_whole = [&](int t, int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)kp[j], (attn_lds_ptr_t)(smem + buf * TILE + (w + 4 * j) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((attn_gbl_ptr_t)vp[j], (attn_lds_ptr_t)(smem + (2 + buf) * TILE + (w + 4 * j) * 1024), 16, 0, 0);
-      kp[j] += kstep;
-      vp[j] += vstep;
+      attn_dma16(rsK, smem + buf * TILE + (w + 4 * j) * 1024, kvo[j], t * kstep);
+      attn_dma16(rsV, smem + (2 + buf) * TILE + (w + 4 * j) * 1024, vvo[j], t * vstep);
     }
   };
 
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
 
   const int ntiles = (p.Nkv + KVB - 1) / KVB;
   const int nfull = p.Nkv / KVB;             // tiles with 64 real keys
-  if (nfull > 0) dma_whole(0); else dma_tile(0, 0);
+  if (nfull > 0) dma_whole(0, 0); else dma_tile(0, 0);
   V8 qf[QW][4];
   int qrow[QW];
   // Round 6: the Q loads are issued BEHIND the first K / V tile's LDS-DMA (above), not in front of it: the two global round trips of a block's prologue
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel7(AttnP p, const char* 
     const int kv0 = t * KVB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of tile t has landed
     __syncthreads();                                     // ... everybody's has, and nobody reads buffer buf^1 any more
-    if (t + 1 < nfull) dma_whole(buf ^ 1);                       // the next tile has 64 real keys
+    if (t + 1 < nfull) dma_whole(t + 1, buf ^ 1);                    // the next tile has 64 real keys
     else if (t + 1 < ntiles) dma_tile(kv0 + KVB, buf ^ 1);       // the ragged last tile: clamped rows
     const char* kt = smem + buf * TILE;
     const char* vt = smem + (2 + buf) * TILE;

@@ -15,8 +15,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int MIX>
+template <int MIXB>
 __global__ __launch_bounds__(256, 2) void k(float* out, const char* src, long src_bytes, int stages) {
+  constexpr bool BUF = MIXB >= 1000;          // 1000 + MIX: the same mode with descriptor addressing (raw_ptr_buffer_load_lds, 32-bit lane offset)
+  constexpr int MIX = MIXB % 1000;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)src_bytes, 0x00020000);
+  auto ld = [&](unsigned long off, char* lds) {
+    if constexpr (BUF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds, 16, (int)(unsigned)off, 0, 0, 0);
+    else __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + off), (lds_ptr_t)lds, 16, 0, 0);
+  };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const char* src, long sr
     auto dma = [&](int buf) {
 #pragma unroll
       for (int d = 0; d < 8; ++d)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ((goff + d * 1024) & (src_bytes - 1))), (lds_ptr_t)(smem + ((d & 1) * 2 + buf) * 16384 + (w * 32 + (d >> 1) * 8) * 128), 16, 0, 0);
+        ld((goff + d * 1024) & (src_bytes - 1), smem + ((d & 1) * 2 + buf) * 16384 + (w * 32 + (d >> 1) * 8) * 128);
       goff = (goff + 8192) & (src_bytes - 1);
     };
     auto mm = [&](int j4) {
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const char* src, long sr
   } else if constexpr (MIX == 6 || MIX == 7) {
     // the pieces SPREAD over the stage: one global_load_lds after every 8th MFMA (MIX 6) / after every 8th MFMA but never first in a k-group (MIX 7)
     auto piece = [&](int buf, int d) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ((goff + d * 1024) & (src_bytes - 1))), (lds_ptr_t)(smem + ((d & 1) * 2 + buf) * 16384 + (w * 32 + (d >> 1) * 8) * 128), 16, 0, 0);
+      ld((goff + d * 1024) & (src_bytes - 1), smem + ((d & 1) * 2 + buf) * 16384 + (w * 32 + (d >> 1) * 8) * 128);
     };
     for (int s = 0; s < stages; ++s) {
       const int buf = s & 1;
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const char* src, long sr
     // piece d right behind MFMA number P0 + d * STEP of the stage (MIX = 100 + 10 * STEP + P0)
     constexpr int STEP = (MIX - 100) / 10, P0 = (MIX - 100) % 10;
     auto piece = [&](int buf, int d) {
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ((goff + d * 1024) & (src_bytes - 1))), (lds_ptr_t)(smem + ((d & 1) * 2 + buf) * 16384 + (w * 32 + (d >> 1) * 8) * 128), 16, 0, 0);
+      ld((goff + d * 1024) & (src_bytes - 1), smem + ((d & 1) * 2 + buf) * 16384 + (w * 32 + (d >> 1) * 8) * 128);
     };
     for (int s = 0; s < stages; ++s) {
       const int buf = s & 1;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const char* src, long sr
       if (MIX != 4)
 #pragma unroll
       for (int d = 0; d < 8; ++d)
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + ((goff + d * 1024) & (src_bytes - 1))), (lds_ptr_t)(smem + ((d & 1) * 2 + (buf ^ 1)) * 16384 + (w * 32 + (d >> 1) * 8) * 128), 16, 0, 0);
+        ld((goff + d * 1024) & (src_bytes - 1), smem + ((d & 1) * 2 + (buf ^ 1)) * 16384 + (w * 32 + (d >> 1) * 8) * 128);
       goff = (goff + 8192) & (src_bytes - 1);
     }
 #pragma unroll
@@ -206,6 +213,9 @@ int main(int argc, char** argv) {
     run<2>("N(0,1), + reads + 8 global_load_lds + vmcnt(0) + barrier per stage, 2 waves", 512, out, rsrc, src_bytes, secs);
     run<2>("zeros,  + reads + 8 global_load_lds + vmcnt(0) + barrier per stage, 2 waves", 512, out, zsrc, src_bytes, secs);
     run<3>("N(0,1), same work, barrier inside the stage (fragments prefetched across it), 2 waves", 512, out, rsrc, src_bytes, secs);
+    run<1002>("N(0,1), L2, DESCRIPTOR addressing: reads + 8 buffer_load lds as a burst + vmcnt(0) + barrier, 2 waves", 512, out, rsrc, hot, secs);
+    run<1180>("N(0,1), L2, DESCRIPTOR addressing: piece d behind MFMA 0 + 8 d, 2 waves", 512, out, rsrc, hot, secs);
+    run<180>("N(0,1), L2: piece d behind MFMA 0 + 8 d, 2 waves", 512, out, rsrc, hot, secs);
     run<110>("N(0,1), L2: piece d behind MFMA 0 + 1 d, 2 waves", 512, out, rsrc, hot, secs);
     run<120>("N(0,1), L2: piece d behind MFMA 0 + 2 d, 2 waves", 512, out, rsrc, hot, secs);
     run<141>("N(0,1), L2: piece d behind MFMA 1 + 4 d, 2 waves", 512, out, rsrc, hot, secs);
