@@ -361,33 +361,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel6(AttnP p, int q_chunk)
         for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
       }
       float psum = 0.f;
-      V8 pf[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float e0 = __builtin_amdgcn_exp2f(s[i][r]);
-          const float e1 = __builtin_amdgcn_exp2f(s[i][r + 1]);
-          psum += e0 + e1;
-          const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
-          pf[i][r >> 3][r & 7] = pk[0];
-          pf[i][r >> 3][(r & 7) + 1] = pk[1];
-        }
-      l_run += psum;
-
-      // ---- O^T += V^T · P^T
+      // block (i, k2) = the tile's keys 16 (2 i + k2) .. + 15 = registers 8 k2 .. 8 k2 + 7 of s[i]: its probabilities, then O^T += V^T · P^T for it.
+      // Round 6: a block without a real key is skipped.  77 text tokens are one whole tile + 13 keys of the second: 3 of its 4 blocks get no
+      // exponentials, no conversions and no P·V MFMAs — 80 exponentials per lane and 32-row step instead of 128, in a loop that is bound by them.
+      // A uniform branch (Nkv is a kernel argument); what is skipped were exact zeros (2^-1e30, 0 · V): the same output (a sum that is exactly -0
+      // may come out +0).
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
+          if (kv0 + 16 * (2 * i + k2) >= p.Nkv) continue;      // no real key: its probabilities are exact zeros
+          V8 pf;
+#pragma unroll
+          for (int r = 8 * k2; r < 8 * k2 + 8; r += 2) {
+            const float e0 = __builtin_amdgcn_exp2f(s[i][r]);
+            const float e1 = __builtin_amdgcn_exp2f(s[i][r + 1]);
+            psum += e0 + e1;
+            const T2 pk = __builtin_convertvector(F2{e0, e1}, T2);
+            pf[r & 7] = pk[0];
+            pf[(r & 7) + 1] = pk[1];
+          }
           const int c0 = i * 4 + k2 * 2 + hi;
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
             const int row = dt * 32 + l31;
             const V8 vf = *(const V8*)(vt + row * 128 + ((c0 ^ ((row >> 1) & 7)) << 4));
-            o[dt] = Vec<T>::mfma32(vf, pf[i][k2], o[dt]);
+            o[dt] = Vec<T>::mfma32(vf, pf, o[dt]);
           }
         }
+      l_run += psum;
     }
 
     // ---- O: normalise, 16 bits, transpose through the wave's LDS strip, row-contiguous 16-byte stores
