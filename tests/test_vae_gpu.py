@@ -151,6 +151,45 @@ def test_fp32_kernels_match_torch_fp32(dev):
     assert torch.equal(ops.cast_f32(h.to(dev)).cpu(), h.float())
 
 
+def test_fp32_conv_addresses_beyond_32_bits_and_tiles_across_images(dev):
+    """conv_f32_kernel's descriptor addressing (round 6): 32-bit lane offsets from the first image a 128-row tile touches.  (a) images smaller than a
+    tile — one tile spans up to FBM / (H W) + 1 images, with and without the fused 2x upsample; (b) an input of 5.4 GB (5 x 1024 x 1024 x 256 fp32:
+    the shape of the VAE's last up block at batch 5): the descriptor of a tile in the last image starts 4.3 GB into the tensor and its range field
+    exceeds 2^31.  (b) is checked on sampled output pixels — corners, image borders, the last pixel of the last image — against a float64 dot product."""
+    g = torch.Generator().manual_seed(1)
+    for (B, H, Cin, Cout, k, ups) in [(5, 8, 32, 64, 3, False), (3, 4, 64, 128, 3, True), (7, 5, 32, 32, 1, False), (9, 3, 32, 96, 3, False)]:
+        x = torch.randn(B, H, H, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) * (k * k * Cin) ** -0.5
+        b = torch.randn(Cout, generator=g)
+        y = ops.conv2d_f32(x.to(dev), ops.pack_conv_weight(w.to(dev)), k, upsample=ups, bias=b.to(dev))
+        xin = x.permute(0, 3, 1, 2)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        ref = F.conv2d(xin.double(), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
+        err = (y.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5, (B, H, Cin, Cout, k, ups, err)
+    B, H, Cin, Cout = 5, 1024, 256, 128
+    gd = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(B, H, H, Cin, generator=gd, device=dev)
+    assert x.numel() * 4 > 5 * 2 ** 30
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
+    y = ops.conv2d_f32(x, ops.pack_conv_weight(w.to(dev)), 3)
+    pts = [(0, 0, 0), (0, H - 1, H - 1), (1, 0, 0), (2, 511, 513), (3, H - 1, 0), (4, 0, H - 1), (4, 777, 3), (4, H - 1, H - 1), (4, H - 2, H - 2)]
+    pts += [(int(torch.randint(0, B, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, H, (1,), generator=g))) for _ in range(24)]
+    wd = w.double()
+    for (bi, yy, xx) in pts:
+        acc = torch.zeros(Cout, dtype=torch.float64)
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                iy, ix = yy + dy, xx + dx
+                if 0 <= iy < H and 0 <= ix < H:
+                    acc += wd[:, :, dy + 1, dx + 1] @ x[bi, iy, ix].cpu().double()
+        err = (y[bi, yy, xx].cpu().double() - acc).abs().max().item()
+        assert err < 2e-5, (bi, yy, xx, err)
+    del x, y
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("cfg_name", ["tiny", "sdxl"])
 def test_upcast_decode_matches_oracle(dev, cfg_name):
     """upcast=True = the reference's decode (lora_pipeline.py:639-652): post_quant_conv / conv_in / mid block in fp16, up blocks,
