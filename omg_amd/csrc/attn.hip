@@ -599,7 +599,7 @@ extern "C" int omg_attn_fwd(const omg_attn_args* a, void* stream) {
     // attn_fwd_kernel7 addresses a (sample, head) slice of K / V with 32-bit offsets behind a buffer descriptor
     OMG_REQUIRE(((long)a->Nkv * a->ldk + 64) * 2 < 0x7fffffffL && ((long)a->Nkv * a->ldv + 64) * 2 < 0x7fffffffL, "omg_attn_fwd: a K / V slice beyond 2 GB");
     OMG_REQUIRE(a->ldv % 8 == 0 && a->v_bstride % 8 == 0, "omg_attn_fwd: V strides must be multiples of 8 elements");
-    OMG_REQUIRE(a->Nkv > 128, "omg_attn_fwd: row-major V needs more than 128 keys (pass Vt from omg_transpose_v below that)");
+    OMG_REQUIRE(a->Nkv > 128 || g_attn_variant == 7, "omg_attn_fwd: row-major V needs more than 128 keys (pass Vt from omg_transpose_v below that)");
     dim3 grid7((a->Nq + 255) / 256, a->heads, a->B);
     const int xcd_order = g_attn_natural_order ? 0 : 1;
     if (a->dtype == OMG_F16) OMG_LAUNCH(attn_fwd_kernel7<f16>, grid7, dim3(256), 0, s, p, (const char*)a->V, (long)a->ldv, (long)a->v_bstride, xcd_order);
