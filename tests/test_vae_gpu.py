@@ -171,7 +171,7 @@ def test_fp32_conv_addresses_beyond_32_bits_and_tiles_across_images(dev):
     B, H, Cin, Cout = 5, 1024, 256, 128
     gd = torch.Generator(device=dev).manual_seed(2)
     x = torch.randn(B, H, H, Cin, generator=gd, device=dev)
-    assert x.numel() * 4 > 5 * 2 ** 30
+    assert x.numel() * 4 > 4 * 2 ** 30                      # beyond any 32-bit byte offset
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
     y = ops.conv2d_f32(x, ops.pack_conv_weight(w.to(dev)), 3)
     pts = [(0, 0, 0), (0, H - 1, H - 1), (1, 0, 0), (2, 511, 513), (3, H - 1, 0), (4, 0, H - 1), (4, 777, 3), (4, H - 1, H - 1), (4, H - 2, H - 2)]
