@@ -17,7 +17,8 @@
 // the stage is used exactly once.  The product order differs from a plain k = 0, 1, 2, ... loop; fp32 addition is not
 // associative, so the result equals an fp32 reference to rounding (1e-6 relative), not bitwise.
 // The accumulators hold the TRANSPOSED tile (mfma(W, A)): a lane owns one output row and runs of 4 consecutive channels = one
-// 16-byte store.  64 MFMAs x 64 cycles per wave and stage against 16 ds_read_b128: MFMA-bound by a wide margin.
+// 16-byte store.  64 MFMAs x 64 cycles per wave and stage against 16 ds_read_b128: MFMA-bound by a wide margin — what kept rounds 2-5 at 124 TF/s
+// (0.79 of the peak) was the ISSUE cost of the stage's eight LDS-DMA pieces (comment above the kernel); round 6: 141-143 TF/s = 0.90-0.91.
 #include "common.h"
 
 namespace {
