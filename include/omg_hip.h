@@ -210,7 +210,9 @@ typedef struct {
   /* ABI 6: V ROW-MAJOR — [B, Nkv, (head, 64)] with row stride ldv and batch stride v_bstride (elements, both % 8 == 0), i.e. the V
    * columns of the fused QKV projection's output exactly as omg_gemm wrote them.  When given and Nkv > 128 (self-attention) the kernel
    * stages it like K and transposes on the LDS read (ds_read_b64_tr_b16): no omg_transpose_v pass, Vt / Nkv_pad may be NULL / 0.
-   * With Nkv <= 128 pass Vt (the resident-K/V kernels want the V^T image); V alone is rejected there.  NULL = ABI 5 behaviour. */
+   * With Nkv <= 128 pass Vt (the resident-K/V kernels want the V^T image); V alone is rejected there.  NULL = ABI 5 behaviour.
+   * The row-major path addresses one (sample, head) slice of K / of V with 32-bit offsets: Nkv * ldk * 2 and Nkv * ldv * 2 bytes must stay below 2 GB
+   * (OMG_EINVAL otherwise; 16 384 keys of a 3 840-wide fused projection are 126 MB). */
   const void* V; int64_t ldv; int64_t v_bstride;
 } omg_attn_args;
 
@@ -264,7 +266,8 @@ int omg_groupnorm_mx8(int dtype, const void* X1, int C1, const void* X2, int C2,
 typedef struct {
   int32_t B, Hin, Win, Cin;   /* Cin % 32 == 0                                        */
   int32_t Hout, Wout, Cout;   /* Hout = Hin * (upsample ? 2 : 1); Cout % 4 == 0       */
-  int32_t ksize, upsample;
+  int32_t ksize, upsample;    /* X may exceed 4 GB: the kernel addresses it from the first image a 128-pixel tile touches; ONE image (Hin * Win * Cin * 4 bytes)
+                                 must stay below ~2 GB and the packed weight below 2 GB (OMG_EINVAL otherwise) */
   const void* X; const void* W; const void* bias; const void* residual;   /* fp32; bias / residual may be NULL */
   void* Y;                    /* [B, Hout, Wout, Cout] fp32                           */
 } omg_conv2d_f32_args;
